@@ -1,0 +1,76 @@
+"""ctypes binding of libmedmamba_hip.so (C ABI: include/medmamba_hip.h).
+
+There is deliberately NO fallback: if the shared library is missing or a kernel launch fails the
+caller gets an exception.  PyTorch is only the owner of device memory and streams here.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "lib", "libmedmamba_hip.so")
+
+_f32p = ctypes.c_void_p
+
+
+class ScanArgs(ctypes.Structure):
+    """Mirror of `struct mm_scan_args` (include/medmamba_hip.h)."""
+    _fields_ = [
+        ("batch", ctypes.c_int32), ("dim", ctypes.c_int32), ("L", ctypes.c_int32), ("N", ctypes.c_int32),
+        ("G", ctypes.c_int32), ("delta_softplus", ctypes.c_int32),
+        ("u", _f32p), ("delta", _f32p), ("A", _f32p), ("B", _f32p), ("C", _f32p), ("D", _f32p),
+        ("delta_bias", _f32p), ("out", _f32p), ("x_chk", _f32p),
+        ("u_sb", ctypes.c_int64), ("u_sd", ctypes.c_int64),
+        ("delta_sb", ctypes.c_int64), ("delta_sd", ctypes.c_int64),
+        ("B_sb", ctypes.c_int64), ("B_sg", ctypes.c_int64), ("B_sn", ctypes.c_int64),
+        ("C_sb", ctypes.c_int64), ("C_sg", ctypes.c_int64), ("C_sn", ctypes.c_int64),
+        ("dout", _f32p), ("du", _f32p), ("ddelta", _f32p), ("dA", _f32p), ("dB", _f32p), ("dC", _f32p),
+        ("dD", _f32p), ("ddelta_bias", _f32p),
+        ("variant", ctypes.c_int32), ("reserved", ctypes.c_int32),
+    ]
+
+
+# every symbol include/medmamba_hip.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "mm_abi_version": (ctypes.c_int, []),
+    "mm_scan_chunk": (ctypes.c_int, []),
+    "mm_status_string": (ctypes.c_char_p, [ctypes.c_int]),
+    "mm_scan_fwd": (ctypes.c_int, [ctypes.POINTER(ScanArgs), ctypes.c_void_p]),
+    "mm_scan_bwd": (ctypes.c_int, [ctypes.POINTER(ScanArgs), ctypes.c_void_p]),
+}
+
+_lib = None
+
+
+class MedMambaHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load the library (once). Raises MedMambaHipError if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise MedMambaHipError(
+                f"{SO_PATH} not found: build it with `python -m medmamba_amd.build` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        try:
+            handle = ctypes.CDLL(SO_PATH)
+        except OSError as e:  # pragma: no cover
+            raise MedMambaHipError(f"cannot load {SO_PATH}: {e}") from e
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(handle, name)      # AttributeError if the .so is stale
+            fn.restype, fn.argtypes = res, args
+        if handle.mm_abi_version() != 1:
+            raise MedMambaHipError("libmedmamba_hip.so ABI version mismatch; rebuild")
+        _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().mm_status_string(rc).decode()
+        raise MedMambaHipError(f"{what} failed: status {rc} ({msg})")
+
+
+def scan_chunk():
+    return lib().mm_scan_chunk()

@@ -1,0 +1,59 @@
+// extern "C" surface of libmedmamba_hip.so — argument validation + dispatch only (include/medmamba_hip.h).
+#include <hip/hip_runtime.h>
+#include "medmamba_hip.h"
+#include "mm_common.h"
+
+namespace mm {
+int scan_fwd_launch(const mm_scan_args* a, hipStream_t stream);
+int scan_bwd_launch(const mm_scan_args* a, hipStream_t stream);
+}  // namespace mm
+
+namespace {
+inline bool al4(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 3) == 0; }
+
+int check_common(const mm_scan_args* a) {
+  if (!a) return MM_ERR_NULL;
+  if (a->batch <= 0 || a->dim <= 0 || a->L <= 0 || a->N <= 0 || a->G <= 0) return MM_ERR_SHAPE;
+  if (a->dim % a->G != 0) return MM_ERR_SHAPE;
+  if (a->N != mm::kNState) return MM_ERR_UNSUPPORTED;   // d_state = 16 on every MedMamba path (MedMamba.py:329,457)
+  if (!a->u || !a->delta || !a->A || !a->B || !a->C) return MM_ERR_NULL;
+  if (!al4(a->u) || !al4(a->delta) || !al4(a->A) || !al4(a->B) || !al4(a->C)) return MM_ERR_ALIGN;
+  return MM_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int mm_abi_version(void) { return MM_ABI_VERSION; }
+int mm_scan_chunk(void) { return mm::kChunk; }
+
+const char* mm_status_string(int s) {
+  switch (s) {
+    case MM_OK: return "ok";
+    case MM_ERR_NULL: return "required pointer is NULL";
+    case MM_ERR_SHAPE: return "bad shape";
+    case MM_ERR_UNSUPPORTED: return "unsupported variant";
+    case MM_ERR_ALIGN: return "misaligned pointer";
+    case MM_ERR_WORKSPACE: return "workspace missing";
+    default: return s > 0 ? hipGetErrorString((hipError_t)s) : "unknown status";
+  }
+}
+
+int mm_scan_fwd(const mm_scan_args* a, void* stream) {
+  int rc = check_common(a);
+  if (rc) return rc;
+  if (!a->out) return MM_ERR_NULL;
+  return mm::scan_fwd_launch(a, (hipStream_t)stream);
+}
+
+int mm_scan_bwd(const mm_scan_args* a, void* stream) {
+  int rc = check_common(a);
+  if (rc) return rc;
+  if (!a->dout || !a->du || !a->ddelta || !a->dA || !a->dB || !a->dC) return MM_ERR_NULL;
+  if (a->D && !a->dD) return MM_ERR_NULL;
+  if (a->delta_bias && !a->ddelta_bias) return MM_ERR_NULL;
+  if (!a->x_chk) return MM_ERR_WORKSPACE;
+  return mm::scan_bwd_launch(a, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,128 @@
+"""`selective_scan_fn` — same name, signature and error behaviour as
+`mamba_ssm.ops.selective_scan_interface.selective_scan_fn`, the operator MedMamba calls at
+MedMamba.py:273-279 (imported at MedMamba.py:12), backed by the gfx950 HIP kernels in
+libmedmamba_hip.so through the C ABI (include/medmamba_hip.h).
+
+Only the variant that exists on the MedMamba path is implemented natively:
+real A, B/C of shape (batch, G, N, L), z=None, return_last_state=False, N = 16, fp32.
+Anything else raises NotImplementedError; CPU tensors raise RuntimeError (no CPU fallback).
+"""
+import torch
+
+from . import _lib
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _check_inputs(u, delta, A, B, C, D, z, delta_bias, return_last_state):
+    if z is not None:
+        raise NotImplementedError("z gating is not on the MedMamba path (MedMamba.py:275 passes z=None)")
+    if return_last_state:
+        raise NotImplementedError("return_last_state=True is not on the MedMamba path (MedMamba.py:278)")
+    if A.is_complex():
+        raise NotImplementedError("complex A is not on the MedMamba path (MedMamba.py:28)")
+    if B.dim() != 4 or C.dim() != 4:
+        raise NotImplementedError("only variable, grouped B/C of shape (batch, G, N, L) are supported")
+    if not u.is_cuda:
+        raise RuntimeError("selective_scan_fn: tensors must live on a HIP device "
+                           "(medmamba_amd has no CPU path; the CPU oracle lives under oracle/ for tests only)")
+    batch, dim, L = u.shape
+    N, G = A.shape[1], B.shape[1]
+    if delta.shape != u.shape or A.shape[0] != dim or B.shape != (batch, G, N, L) or C.shape != B.shape:
+        raise RuntimeError(f"selective_scan_fn: inconsistent shapes u{tuple(u.shape)} delta{tuple(delta.shape)} "
+                           f"A{tuple(A.shape)} B{tuple(B.shape)} C{tuple(C.shape)}")
+    if dim % G != 0:
+        raise RuntimeError("selective_scan_fn: dim must be divisible by the number of B/C groups")
+    if N != 16:
+        raise NotImplementedError("only d_state = 16 is implemented (every MedMamba block: MedMamba.py:329,457)")
+    for name, t in (("D", D), ("delta_bias", delta_bias)):
+        if t is not None and t.shape != (dim,):
+            raise RuntimeError(f"selective_scan_fn: {name} must have shape ({dim},)")
+
+
+def _f32_rows(t):
+    """fp32 with unit stride in the last dim (mamba_ssm copies in exactly this case too)."""
+    t = t.float()
+    return t if t.stride(-1) == 1 else t.contiguous()
+
+
+def _fill_common(a, u, delta, A, B, C, D, delta_bias, delta_softplus):
+    batch, dim, L = u.shape
+    a.batch, a.dim, a.L, a.N, a.G = batch, dim, L, A.shape[1], B.shape[1]
+    a.delta_softplus = int(bool(delta_softplus))
+    a.u, a.delta, a.A, a.B, a.C = u.data_ptr(), delta.data_ptr(), A.data_ptr(), B.data_ptr(), C.data_ptr()
+    a.D, a.delta_bias = _ptr(D), _ptr(delta_bias)
+    a.u_sb, a.u_sd = u.stride(0), u.stride(1)
+    a.delta_sb, a.delta_sd = delta.stride(0), delta.stride(1)
+    a.B_sb, a.B_sg, a.B_sn = B.stride(0), B.stride(1), B.stride(2)
+    a.C_sb, a.C_sg, a.C_sn = C.stride(0), C.stride(1), C.stride(2)
+
+
+class SelectiveScanFn(torch.autograd.Function):
+    """Autograd wrapper around mm_scan_fwd / mm_scan_bwd.
+
+    Saved for backward: u, delta, A, B, C, D, delta_bias and the state checkpoints x_chk
+    (batch, dim, ceil(L/16), 16) that the forward kernel writes — the backward kernel recomputes the
+    states of each 16-step chunk from them instead of storing all L x 16 states."""
+
+    @staticmethod
+    def forward(ctx, u, delta, A, B, C, D=None, delta_bias=None, delta_softplus=False, variant=0):
+        u, delta, B, C = _f32_rows(u), _f32_rows(delta), _f32_rows(B), _f32_rows(C)
+        A = A.float().contiguous()
+        D = None if D is None else D.float().contiguous()
+        delta_bias = None if delta_bias is None else delta_bias.float().contiguous()
+        batch, dim, L = u.shape
+        need_grad = any(ctx.needs_input_grad[:7])
+        out = torch.empty((batch, dim, L), device=u.device, dtype=torch.float32)
+        x_chk = None
+        if need_grad:
+            chunk = _lib.scan_chunk()
+            x_chk = torch.empty((batch, dim, (L + chunk - 1) // chunk, A.shape[1]), device=u.device,
+                                dtype=torch.float32)
+        a = _lib.ScanArgs()
+        _fill_common(a, u, delta, A, B, C, D, delta_bias, delta_softplus)
+        a.out, a.x_chk, a.variant = out.data_ptr(), _ptr(x_chk), int(variant)
+        with torch.cuda.device(u.device):
+            rc = _lib.lib().mm_scan_fwd(a, torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "mm_scan_fwd")
+        if need_grad:
+            ctx.save_for_backward(u, delta, A, B, C, D, delta_bias, x_chk)
+            ctx.delta_softplus = delta_softplus
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        u, delta, A, B, C, D, delta_bias, x_chk = ctx.saved_tensors
+        dout = dout.float().contiguous()
+        batch, dim, L = u.shape
+        G, N = B.shape[1], A.shape[1]
+        dev = u.device
+        du, ddelta = torch.empty_like(dout), torch.empty_like(dout)
+        # accumulated with atomics across batch / channel tiles -> zero-filled here (header contract)
+        dA = torch.zeros((dim, N), device=dev, dtype=torch.float32)
+        dB = torch.zeros((batch, G, N, L), device=dev, dtype=torch.float32)
+        dC = torch.zeros((batch, G, N, L), device=dev, dtype=torch.float32)
+        dD = None if D is None else torch.zeros((dim,), device=dev, dtype=torch.float32)
+        dbias = None if delta_bias is None else torch.zeros((dim,), device=dev, dtype=torch.float32)
+        a = _lib.ScanArgs()
+        _fill_common(a, u, delta, A, B, C, D, delta_bias, ctx.delta_softplus)
+        a.x_chk, a.dout = x_chk.data_ptr(), dout.data_ptr()
+        a.du, a.ddelta, a.dA, a.dB, a.dC = (du.data_ptr(), ddelta.data_ptr(), dA.data_ptr(), dB.data_ptr(),
+                                            dC.data_ptr())
+        a.dD, a.ddelta_bias = _ptr(dD), _ptr(dbias)
+        with torch.cuda.device(dev):
+            rc = _lib.lib().mm_scan_bwd(a, torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "mm_scan_bwd")
+        return du, ddelta, dA, dB, dC, dD, dbias, None, None
+
+
+def selective_scan_fn(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=False,
+                      return_last_state=False):
+    """Drop-in for mamba_ssm's selective_scan_fn on the variant MedMamba uses (MedMamba.py:273-279).
+
+    u, delta: (batch, dim, L); A: (dim, 16); B, C: (batch, G, 16, L) (may be non-contiguous views with
+    unit stride along L); D, delta_bias: (dim,).  Returns (batch, dim, L) float32, contiguous."""
+    _check_inputs(u, delta, A, B, C, D, z, delta_bias, return_last_state)
+    return SelectiveScanFn.apply(u, delta, A, B, C, D, delta_bias, delta_softplus, 0)

@@ -1,0 +1,63 @@
+"""CPU: the C-ABI library builds/loads and exports every symbol include/medmamba_hip.h declares;
+host-side argument checking of the operator mirrors the reference's (no compute without a GPU)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import ROOT
+import medmamba_amd
+from medmamba_amd import _lib
+
+
+def _declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "medmamba_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(mm_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_library_exports_every_declared_symbol():
+    from medmamba_amd.build import build
+    so = build()
+    h = ctypes.CDLL(so)
+    decl = _declared_symbols()
+    assert "mm_scan_fwd" in decl and "mm_scan_bwd" in decl
+    for name in decl:
+        assert hasattr(h, name), name
+        assert name in _lib.SYMBOLS, f"{name} declared in the header but not bound in _lib.SYMBOLS"
+    assert set(_lib.SYMBOLS) <= set(decl)
+    assert _lib.lib().mm_abi_version() == 1
+    assert _lib.scan_chunk() == 16
+    assert b"unsupported" in _lib.lib().mm_status_string(-3)
+
+
+def test_struct_layout_matches_header():
+    # 6 int32 + 9 pointers + 10 int64 + 8 pointers + 2 int32 (LP64)
+    assert ctypes.sizeof(_lib.ScanArgs) == 6 * 4 + 9 * 8 + 10 * 8 + 8 * 8 + 2 * 4
+
+
+def test_bad_arguments_are_rejected_without_launch():
+    a = _lib.ScanArgs()
+    assert _lib.lib().mm_scan_fwd(None, None) == -1
+    a.batch, a.dim, a.L, a.N, a.G = 1, 6, 8, 16, 4        # dim % G != 0
+    assert _lib.lib().mm_scan_fwd(a, None) == -2
+    a.dim, a.N = 8, 8                                       # N != 16
+    assert _lib.lib().mm_scan_fwd(a, None) == -3
+    a.N = 16                                                # null operands
+    assert _lib.lib().mm_scan_fwd(a, None) == -1
+    with pytest.raises(_lib.MedMambaHipError):
+        _lib.check(-3, "x")
+
+
+def test_operator_has_no_cpu_fallback_and_mirrors_reference_errors():
+    u = torch.zeros(1, 8, 8); A = torch.zeros(8, 16); B = torch.zeros(1, 4, 16, 8)
+    with pytest.raises(RuntimeError, match="HIP device"):
+        medmamba_amd.selective_scan_fn(u, u, A, B, B)
+    with pytest.raises(NotImplementedError):
+        medmamba_amd.selective_scan_fn(u, u, A, B, B, z=u)
+    with pytest.raises(NotImplementedError):
+        medmamba_amd.selective_scan_fn(u, u, A, B, B, return_last_state=True)
+    with pytest.raises(NotImplementedError):
+        medmamba_amd.selective_scan_fn(u, u, A, torch.zeros(1, 16, 8), B)
