@@ -1,20 +1,26 @@
 // Selective-scan forward for gfx950 (MI355X).  Replaces mamba_ssm's selective_scan_cuda.fwd behind
 // selective_scan_fn (reference call site MedMamba.py:273-279; arithmetic temp.py:57-139).
 //
-// Mapping (wave64):  one workgroup = one (batch, direction-group) pair x a range of CW channels;
-//   one wavefront   = CH = 4*NS channels; lane = (channel c = lane / SG, state group g = lane % SG),
-//                     SG = 16/NS lanes share a channel, each lane carries NS of the 16 states in VGPRs.
-// Data movement per tile of 64 steps:
-//   u, delta  : global (rows contiguous along L) --float4, 16 lanes per row--> regs --softplus, delta*u-->
-//               wave-private LDS [channel][t] (row stride 68 floats)  --b128 by (c,t..t+3)--> recurrence
-//   B, C      : global --float4--> workgroup-shared LDS [n][t], double buffered, one barrier per tile;
-//               they are shared by every channel of the direction (temp.py:95-98), so they are read
-//               from HBM/L2 once per workgroup instead of once per channel
-//   y         : DPP butterfly over the SG lanes of a channel -> LDS (in place of delta*u) -> + D*u ->
-//               float4 global store with the same coalesced mapping as the loads
-// The next tile's global loads are issued before the current tile's recurrence (register prefetch).
-// The recurrence is sequential in registers: per state-step 1 v_exp_f32 + 4 VALU, no parallel-scan
-// work inflation.  Tail / padded steps are made identity steps (delta' = 0 -> a = 1, b = 0).
+// Mapping (wave64): every wavefront is independent (no workgroup barrier anywhere):
+//   wavefront = one (batch, direction-group) pair x CH = 4*NS consecutive channels;
+//   lane = (channel c = lane / SG, state group g = lane % SG), SG = 16/NS lanes share a channel and each
+//   lane carries NS of the 16 states in VGPRs for the whole sequence.
+// Data movement per tile of 64 steps, all through wave-private LDS:
+//   u, delta : buffer_load_dwordx4, 16 lanes per row (256 B contiguous per row) -> regs -> softplus,
+//              delta*u -> LDS [channel][t] (row stride 68 floats) -> ds_read_b128 by (c, t..t+3)
+//   B, C     : shared by every channel of the direction (temp.py:95-98): HBM once, then L2 (workgroups of
+//              one (batch, direction) are mapped to the same XCD) -> regs -> LDS [n][t]
+//   y        : DPP butterfly over the SG lanes of a channel -> LDS (in place of delta*u) -> + D*u ->
+//              buffer_store_dwordx4 with the same coalesced mapping as the loads
+// Software pipeline: the next tile's global loads are issued before the current tile's recurrence, the
+// current tile's stores are issued after the next wait point (loads are older than stores in the vmcnt
+// queue, so waiting for the loads never waits for the stores), and inside the recurrence the next 4-step
+// group's LDS operands are read while the current group's arithmetic runs.
+// All global accesses go through bounds-checked buffer descriptors: out-of-range lanes (sequence tail,
+// channel tail) read 0 and drop their stores, so there is no divergent control flow and the compiler can
+// count vmcnt exactly.  Padded steps are identity steps (delta' = 0 -> a = 1, b = 0).
+// Cost per state-step: v_mul, v_exp_f32, v_mul, v_fma, v_fma (measured: ~1.05 ns per VALU issue slot per
+// SIMD with >= 2 waves; the transcendental overlaps other VALU) — no parallel-scan work inflation.
 #include "mm_common.h"
 #include "medmamba_hip.h"
 
@@ -32,36 +38,42 @@ struct FwdParams {
   float* __restrict__ out;
   float* __restrict__ x_chk;
   int64_t u_sb, u_sd, d_sb, d_sd, B_sb, B_sg, B_sn, C_sb, C_sg, C_sn;
-  int dim, L, G, H;       // H = channels per group
-  int CW, ncw;            // channels per workgroup, workgroups per (batch, group)
+  int batch, dim, L, G, H;  // H = channels per group
+  int wpg;                  // waves per (batch, group)
   int ntiles, nchk;
-  int softplus;
+  int nwaves_total;
+  int dbg;   // timing-only ablation bits (bench diagnostics; results are wrong when set): 1 no y store, 2 no recurrence
 };
 
-template <bool VEC>
-__device__ __forceinline__ float4 load4(const float* __restrict__ p, int t, int L) {
-  // p points at element t of a row of length L (t is a multiple of 4)
-  if constexpr (VEC) {
-    return t < L ? *reinterpret_cast<const float4*>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
-  } else {
-    float4 v;
-    v.x = t + 0 < L ? p[0] : 0.f;
-    v.y = t + 1 < L ? p[1] : 0.f;
-    v.z = t + 2 < L ? p[2] : 0.f;
-    v.w = t + 3 < L ? p[3] : 0.f;
-    return v;
-  }
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+// NOTE: never __builtin_bit_cast a single ext-vector ELEMENT (v.x): hipcc 7.2 miscompiles it to element 0;
+// bit_cast the whole vector and then take components.
+constexpr int kOOB = 0x7fffffff;   // voffset that always fails the range check
+
+__device__ __forceinline__ rsrc_t make_rsrc(const void* base, int64_t bytes) {
+  const int64_t capped = bytes > 0x7ffffff0ll ? 0x7ffffff0ll : bytes;
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)capped, 0x00020000);
 }
 
 template <bool VEC>
-__device__ __forceinline__ void store4(float* __restrict__ p, int t, int L, float4 v) {
+__device__ __forceinline__ float4 bload4(rsrc_t r, int byte_off, bool ok) {
+  // byte_off addresses 4 consecutive floats; VEC: one dwordx4 (row starts are 16-B aligned and L % 4 == 0, so
+  // a quad is entirely in or entirely out of the row); otherwise 4 dword loads with a per-element check.
   if constexpr (VEC) {
-    if (t < L) *reinterpret_cast<float4*>(p) = v;
+    const v4u v = __builtin_amdgcn_raw_buffer_load_b128(r, ok ? byte_off : kOOB, 0, 0);
+    const v4f f = __builtin_bit_cast(v4f, v);
+    return make_float4(f.x, f.y, f.z, f.w);
   } else {
-    if (t + 0 < L) p[0] = v.x;
-    if (t + 1 < L) p[1] = v.y;
-    if (t + 2 < L) p[2] = v.z;
-    if (t + 3 < L) p[3] = v.w;
+    float4 o;
+    const unsigned a0 = __builtin_amdgcn_raw_buffer_load_b32(r, ok ? byte_off : kOOB, 0, 0);
+    const unsigned a1 = __builtin_amdgcn_raw_buffer_load_b32(r, ok ? byte_off + 4 : kOOB, 0, 0);
+    const unsigned a2 = __builtin_amdgcn_raw_buffer_load_b32(r, ok ? byte_off + 8 : kOOB, 0, 0);
+    const unsigned a3 = __builtin_amdgcn_raw_buffer_load_b32(r, ok ? byte_off + 12 : kOOB, 0, 0);
+    o.x = __builtin_bit_cast(float, a0); o.y = __builtin_bit_cast(float, a1);
+    o.z = __builtin_bit_cast(float, a2); o.w = __builtin_bit_cast(float, a3);
+    return o;
   }
 }
 
@@ -69,29 +81,37 @@ __device__ __forceinline__ float f4get(const float4& v, int i) {
   return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w;
 }
 
-// NS: states per lane (1,2,4).  NBC: float4 B/C staging loads per thread.  VEC: L % 4 == 0 and every
-// row 16-B aligned.
-template <int NS, int NBC, bool VEC>
-__global__ __launch_bounds__(768) void scan_fwd_kernel(const FwdParams p) {
+// NS: states per lane (1,2,4).  VEC: L % 4 == 0 and all rows 16-B aligned.  SP: delta_softplus.
+template <int NS, bool VEC, bool SP>
+__global__ __launch_bounds__(256) void scan_fwd_kernel(const FwdParams p) {
   constexpr int SG = kNState / NS;   // lanes per channel
   constexpr int CH = kWave / SG;     // channels per wave (= 4*NS)
   constexpr int NLD = CH / 4;        // float4 row-loads per lane per tensor per tile (= NS)
+  constexpr int WLDS = 2 * CH * kTileStride + 2 * kNState * kTileStride;   // floats of LDS per wave
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int nthreads = blockDim.x;
-  const int cw = blockIdx.x % p.ncw;
-  const int bk = blockIdx.x / p.ncw;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wpb = blockDim.x >> 6;
+  // XCD-aware numbering: blocks b and b+8 share an XCD (its L2); give each XCD a contiguous range of
+  // logical wave ids so that the waves of one (batch, direction) — which all stream the same B/C — meet in one L2.
+  int blk = blockIdx.x;
+  const int nblk = gridDim.x;
+  if ((nblk & 7) == 0) blk = (blk & 7) * (nblk >> 3) + (blk >> 3);
+  const int gw = blk * wpb + wave;                   // logical wave id
+  if (gw >= p.nwaves_total) return;
+  const int cwv = gw % p.wpg;                        // channel tile inside the group
+  const int bk = gw / p.wpg;
   const int grp = bk % p.G, b = bk / p.G;
 
-  float* bc = smem;                                                    // [2][2][16][kTileStride]
-  float* wl = smem + 2 * 2 * kNState * kTileStride + wave * (2 * CH * kTileStride);
-  float* s_dl = wl;                                                    // [CH][kTileStride]
-  float* s_du = wl + CH * kTileStride;                                 // [CH][kTileStride]  (y in place)
+  float* wl = smem + wave * WLDS;
+  float* s_dl = wl;                                   // [CH][kTileStride]   delta'
+  float* s_du = wl + CH * kTileStride;                // [CH][kTileStride]   delta'*u, then y (in place)
+  float* s_bc = wl + 2 * CH * kTileStride;            // [2][16][kTileStride] B, C
 
-  // ---- recurrence-phase identity: lane -> (channel c, state group g)
+  // ---- recurrence identity: lane -> (channel c, state group g)
   const int c = lane / SG, g = lane % SG;
-  const int hc = cw * p.CW + wave * CH + c;        // channel within the group
+  const int hc = cwv * CH + c;                        // channel within the group
   const bool cvalid = hc < p.H;
   const int d = grp * p.H + (cvalid ? hc : 0);
   float A2[NS], x[NS];
@@ -101,41 +121,70 @@ __global__ __launch_bounds__(768) void scan_fwd_kernel(const FwdParams p) {
     x[j] = 0.f;
   }
 
-  // ---- staging-phase identity: lane -> (row r of a 4-row group, float4 column q)
+  // ---- staging identity: lane -> (row r of a 4-row group, float4 column q); rows 4*i + r
   const int r = lane >> 4, q = lane & 15;
-  // rows handled by this lane are 4*i + r: one base per tensor + a wave-uniform step keeps VGPRs low
-  const int hc0 = cw * p.CW + wave * CH + r;
-  const float* ubase = p.u + b * p.u_sb + (int64_t)(grp * p.H + hc0) * p.u_sd;
-  const float* dbase = p.delta + b * p.d_sb + (int64_t)(grp * p.H + hc0) * p.d_sd;
-  float* obase = p.out + ((int64_t)b * p.dim + grp * p.H + hc0) * p.L;
+  const int hc0 = cwv * CH + r;
+  const int d0 = grp * p.H + cwv * CH;               // first channel of this wave (wave-uniform)
+  // descriptors: wave-uniform bases, hardware range check does the tail masking
+  const rsrc_t ru = make_rsrc(p.u + b * p.u_sb + d0 * p.u_sd, ((int64_t)(p.dim - d0 - 1) * p.u_sd + p.L) * 4);
+  const rsrc_t rd = make_rsrc(p.delta + b * p.d_sb + d0 * p.d_sd, ((int64_t)(p.dim - d0 - 1) * p.d_sd + p.L) * 4);
+  const rsrc_t ro = make_rsrc(p.out + ((int64_t)b * p.dim + d0) * p.L, (int64_t)(p.dim - d0) * p.L * 4);
+  const rsrc_t rB = make_rsrc(p.B + b * p.B_sb + grp * p.B_sg, ((int64_t)(kNState - 1) * p.B_sn + p.L) * 4);
+  const rsrc_t rC = make_rsrc(p.C + b * p.C_sb + grp * p.C_sg, ((int64_t)(kNState - 1) * p.C_sn + p.L) * 4);
   float Dv[NLD], bv[NLD];
   bool rvalid[NLD];
+  int uoff[NLD], doff[NLD], ooff[NLD];
 #pragma unroll
   for (int i = 0; i < NLD; ++i) {
     rvalid[i] = hc0 + 4 * i < p.H;
     const int dd = grp * p.H + (rvalid[i] ? hc0 + 4 * i : 0);
     Dv[i] = p.D ? p.D[dd] : 0.f;
     bv[i] = p.bias ? p.bias[dd] : 0.f;
+    uoff[i] = (int)((r + 4 * i) * p.u_sd + 4 * q) * 4;
+    doff[i] = (int)((r + 4 * i) * p.d_sd + 4 * q) * 4;
+    ooff[i] = ((r + 4 * i) * p.L + 4 * q) * 4;
   }
-  const float* Bbase = p.B + b * p.B_sb + grp * p.B_sg;
-  const float* Cbase = p.C + b * p.C_sb + grp * p.C_sg;
+  // B/C staging: 8 float4 per lane per tile: k -> (which = k>>2, n = (k&3)*4 + r, column q)
+  int bcoff[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int n = (k & 3) * 4 + r;
+    bcoff[k] = (int)(n * ((k >> 2) ? p.C_sn : p.B_sn) + 4 * q) * 4;
+  }
 
-  float4 pu[NLD], pd[NLD], pbc[NBC];
+  float4 pu[NLD], pd[NLD], pbc[8];
   auto issue_loads = [&](int t0) {
-    const int t = t0 + 4 * q;
+    const bool tin = VEC ? (t0 + 4 * q < p.L) : true;
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
-      const bool ok = rvalid[i];
-      pu[i] = ok ? load4<VEC>(ubase + 4 * i * p.u_sd + t, t, p.L) : make_float4(0.f, 0.f, 0.f, 0.f);
-      pd[i] = ok ? load4<VEC>(dbase + 4 * i * p.d_sd + t, t, p.L) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if constexpr (VEC) {
+        pu[i] = bload4<true>(ru, uoff[i] + t0 * 4, rvalid[i] && tin);
+        pd[i] = bload4<true>(rd, doff[i] + t0 * 4, rvalid[i] && tin);
+      } else {
+        pu[i] = bload4<false>(ru, uoff[i] + t0 * 4, rvalid[i]);
+        pd[i] = bload4<false>(rd, doff[i] + t0 * 4, rvalid[i]);
+      }
     }
 #pragma unroll
-    for (int k = 0; k < NBC; ++k) {
-      const int idx = tid + k * nthreads;            // 0..511: [which][n][q']
-      if (idx < 512) {
-        const int which = idx >> 8, n = (idx >> 4) & 15, qq = idx & 15;
-        const float* src = which ? Cbase + n * p.C_sn : Bbase + n * p.B_sn;
-        pbc[k] = load4<VEC>(src + t0 + 4 * qq, t0 + 4 * qq, p.L);
+    for (int k = 0; k < 8; ++k) pbc[k] = bload4<VEC>((k >> 2) ? rC : rB, bcoff[k] + t0 * 4, tin);
+  };
+  // NOTE (non-VEC): element-wise tail masking happens below (t + e < L) because a row tail lands in the next row.
+
+  float4 yreg[NLD];
+  auto store_tile = [&](int t0) {
+    const bool st_en = !(p.dbg & 1);   // folded into the range check: no branch, so vmcnt stays countable
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int t = t0 + 4 * q;
+      if constexpr (VEC) {
+        const bool ok = rvalid[i] && t < p.L && st_en;
+        const v4f yv = {yreg[i].x, yreg[i].y, yreg[i].z, yreg[i].w};
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, yv), ro, ok ? ooff[i] + t0 * 4 : kOOB, 0, 0);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, f4get(yreg[i], e)), ro,
+                                                (rvalid[i] && t + e < p.L && st_en) ? ooff[i] + (t0 + e) * 4 : kOOB, 0, 0);
       }
     }
   };
@@ -143,7 +192,6 @@ __global__ __launch_bounds__(768) void scan_fwd_kernel(const FwdParams p) {
   issue_loads(0);
   for (int tile = 0; tile < p.ntiles; ++tile) {
     const int t0 = tile * kTile;
-    const int buf = tile & 1;
     // ---- phase 1: registers -> LDS (delta' and delta'*u), keep D*u for the epilogue
     float4 uD[NLD];
 #pragma unroll
@@ -152,9 +200,9 @@ __global__ __launch_bounds__(768) void scan_fwd_kernel(const FwdParams p) {
       float4 dl, du;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        float raw = f4get(pd[i], e) + bv[i];
-        float v = p.softplus ? softplus_f(raw) : raw;
-        v = (rvalid[i] && t + e < p.L) ? v : 0.f;     // identity step outside the sequence
+        const float raw = f4get(pd[i], e) + bv[i];
+        float v = SP ? softplus_f(raw) : raw;
+        v = (rvalid[i] && t + e < p.L) ? v : 0.f;     // identity step outside the sequence / channel range
         (&dl.x)[e] = v;
         (&du.x)[e] = v * f4get(pu[i], e);
       }
@@ -164,40 +212,49 @@ __global__ __launch_bounds__(768) void scan_fwd_kernel(const FwdParams p) {
       *reinterpret_cast<float4*>(s_du + off) = du;
     }
 #pragma unroll
-    for (int k = 0; k < NBC; ++k) {
-      const int idx = tid + k * nthreads;
-      if (idx < 512) {
-        const int which = idx >> 8, n = (idx >> 4) & 15, qq = idx & 15;
-        *reinterpret_cast<float4*>(bc + ((buf * 2 + which) * kNState + n) * kTileStride + 4 * qq) = pbc[k];
+    for (int k = 0; k < 8; ++k) {
+      const int n = (k & 3) * 4 + r;
+      float4 v = pbc[k];
+      if constexpr (!VEC) {   // zero the elements that belong to the next row
+        const int t = t0 + 4 * q;
+        v.x = t + 0 < p.L ? v.x : 0.f; v.y = t + 1 < p.L ? v.y : 0.f;
+        v.z = t + 2 < p.L ? v.z : 0.f; v.w = t + 3 < p.L ? v.w : 0.f;
       }
+      *reinterpret_cast<float4*>(s_bc + ((k >> 2) * kNState + n) * kTileStride + 4 * q) = v;
     }
+    // the previous tile's stores go out here: older than the loads issued next, so the wait for those
+    // loads (one recurrence later) retires them for free and every path sees the same vmcnt picture
+    if (tile > 0) store_tile(t0 - kTile);
     if (tile + 1 < p.ntiles) issue_loads(t0 + kTile);
-    __syncthreads();
 
-    // ---- phase 2: the recurrence over this tile, 4 steps per iteration
+    // ---- phase 2: the recurrence over this tile, 4 steps per group
     const int tlen = min(kTile, p.L - t0);
-    const int ngroups = (tlen + 3) >> 2;
-    const float* sB = bc + (buf * 2 + 0) * kNState * kTileStride + (g * NS) * kTileStride;
-    const float* sC = bc + (buf * 2 + 1) * kNState * kTileStride + (g * NS) * kTileStride;
-    for (int tg = 0; tg < ngroups; ++tg) {
-      const float4 dl4 = *reinterpret_cast<const float4*>(s_dl + c * kTileStride + 4 * tg);
-      const float4 du4 = *reinterpret_cast<const float4*>(s_du + c * kTileStride + 4 * tg);
-      float4 Bv[NS], Cv[NS];
+    const int ngroups = (p.dbg & 2) ? 0 : (tlen + 3) >> 2;
+    const float* sB = s_bc + (g * NS) * kTileStride;
+    const float* sC = s_bc + (kNState + g * NS) * kTileStride;
+    struct Ops { float4 dl4, du4, Bv[NS], Cv[NS]; };
+    auto load_ops = [&](int tg) {
+      Ops o;
+      o.dl4 = *reinterpret_cast<const float4*>(s_dl + c * kTileStride + 4 * tg);
+      o.du4 = *reinterpret_cast<const float4*>(s_du + c * kTileStride + 4 * tg);
 #pragma unroll
       for (int j = 0; j < NS; ++j) {
-        Bv[j] = *reinterpret_cast<const float4*>(sB + j * kTileStride + 4 * tg);
-        Cv[j] = *reinterpret_cast<const float4*>(sC + j * kTileStride + 4 * tg);
+        o.Bv[j] = *reinterpret_cast<const float4*>(sB + j * kTileStride + 4 * tg);
+        o.Cv[j] = *reinterpret_cast<const float4*>(sC + j * kTileStride + 4 * tg);
       }
+      return o;
+    };
+    auto compute = [&](const Ops& o, int tg) {
       float4 y4;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float dl = f4get(dl4, e), du = f4get(du4, e);
+        const float dl = f4get(o.dl4, e), du = f4get(o.du4, e);
         float y = 0.f;
 #pragma unroll
         for (int j = 0; j < NS; ++j) {
           const float a = __builtin_amdgcn_exp2f(dl * A2[j]);
-          x[j] = fmaf(a, x[j], du * f4get(Bv[j], e));
-          y = fmaf(x[j], f4get(Cv[j], e), y);
+          x[j] = fmaf(a, x[j], du * f4get(o.Bv[j], e));
+          y = fmaf(x[j], f4get(o.Cv[j], e), y);
         }
         (&y4.x)[e] = group_sum<SG>(y);
       }
@@ -208,41 +265,44 @@ __global__ __launch_bounds__(768) void scan_fwd_kernel(const FwdParams p) {
 #pragma unroll
         for (int j = 0; j < NS; ++j) dst[j] = x[j];
       }
+    };
+    // two operand register sets, rotated by hand (a `cur = nxt` copy costs 40 v_mov per group)
+    Ops opA = load_ops(0);
+    for (int tg = 0; tg < ngroups; tg += 2) {
+      Ops opB = load_ops(min(tg + 1, ngroups - 1));
+      __builtin_amdgcn_sched_barrier(0);   // keep the prefetch above the arithmetic it overlaps with
+      compute(opA, tg);
+      __builtin_amdgcn_sched_barrier(0);
+      opA = load_ops(min(tg + 2, ngroups - 1));
+      __builtin_amdgcn_sched_barrier(0);
+      if (tg + 1 < ngroups) compute(opB, tg + 1);
+      __builtin_amdgcn_sched_barrier(0);
     }
 
-    // ---- phase 3: y (+ D*u) LDS -> global, same coalesced mapping as the loads
+    // ---- phase 3: y (+ D*u) LDS -> registers -> global (coalesced like the loads)
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
-      const int t = t0 + 4 * q;
       const float4 y = *reinterpret_cast<const float4*>(s_du + (4 * i + r) * kTileStride + 4 * q);
-      if (rvalid[i])
-        store4<VEC>(obase + (int64_t)4 * i * p.L + t, t, p.L, make_float4(y.x + uD[i].x, y.y + uD[i].y, y.z + uD[i].z, y.w + uD[i].w));
+      yreg[i] = make_float4(y.x + uD[i].x, y.y + uD[i].y, y.z + uD[i].z, y.w + uD[i].w);
     }
   }
+  store_tile((p.ntiles - 1) * kTile);
 }
 
-template <int NS, int NBC, bool VEC>
-int launch(const FwdParams& p, int nblocks, int waves, hipStream_t stream) {
+template <int NS, bool VEC, bool SP>
+int launch(const FwdParams& p, int nblocks, int wpb, hipStream_t stream) {
   constexpr int CH = 4 * NS;
-  const size_t lds = sizeof(float) * (2 * 2 * kNState * kTileStride + (size_t)waves * 2 * CH * kTileStride);
+  const size_t lds = sizeof(float) * (size_t)wpb * (2 * CH * kTileStride + 2 * kNState * kTileStride);
   if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute((const void*)scan_fwd_kernel<NS, NBC, VEC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((scan_fwd_kernel<NS, NBC, VEC>), dim3(nblocks), dim3(waves * 64), lds, stream, p);
+    (void)hipFuncSetAttribute((const void*)scan_fwd_kernel<NS, VEC, SP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((scan_fwd_kernel<NS, VEC, SP>), dim3(nblocks), dim3(wpb * 64), lds, stream, p);
   return (int)hipGetLastError();
 }
 
-template <int NS, bool VEC>
-int launch_nbc(const FwdParams& p, int nblocks, int waves, hipStream_t stream) {
-  const int nbc = (512 + waves * 64 - 1) / (waves * 64);
-  if (nbc <= 1) return launch<NS, 1, VEC>(p, nblocks, waves, stream);
-  if (nbc <= 2) return launch<NS, 2, VEC>(p, nblocks, waves, stream);
-  if (nbc <= 4) return launch<NS, 4, VEC>(p, nblocks, waves, stream);
-  return launch<NS, 8, VEC>(p, nblocks, waves, stream);
-}
-
 template <int NS>
-int launch_vec(const FwdParams& p, int nblocks, int waves, bool vec, hipStream_t stream) {
-  return vec ? launch_nbc<NS, true>(p, nblocks, waves, stream) : launch_nbc<NS, false>(p, nblocks, waves, stream);
+int launch_ns(const FwdParams& p, int nblocks, int wpb, bool vec, bool sp, hipStream_t stream) {
+  if (vec) return sp ? launch<NS, true, true>(p, nblocks, wpb, stream) : launch<NS, true, false>(p, nblocks, wpb, stream);
+  return sp ? launch<NS, false, true>(p, nblocks, wpb, stream) : launch<NS, false, false>(p, nblocks, wpb, stream);
 }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -251,17 +311,15 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 namespace mm {
 
-// Host-side planning: pick states-per-lane and the channel range per workgroup.
-// More lanes per channel (smaller NS) = more wavefronts for short/narrow problems at the price of
-// DPP reduction steps; the target is >= 2 waves per SIMD (2048 waves) chip-wide.
+// Host-side planning: states per lane.  Fewer states per lane = more wavefronts for narrow problems at the
+// price of DPP reduction steps and per-(channel,step) overhead replicated over more lanes.  The VALU reaches
+// its 2-cycle issue rate only with >= 2 waves per SIMD (measured), so aim for >= 2048 waves, ideally >= 3072.
 int plan_fwd_variant(int batch, int G, int H, int L) {
   (void)L;
   const long seqs = (long)batch * G * H;
-  // waves = seqs / (4*NS)
-  if (seqs / 16 >= 4096) return 4;
-  if (seqs / 8 >= 3072) return 2;
-  if (seqs / 16 >= 2048) return 4;
-  if (seqs / 8 >= 1024) return 2;
+  if (seqs / 16 >= 3072) return 4;
+  if (seqs / 8 >= 2048) return 2;
+  if (seqs / 16 >= 1536) return 4;
   return 1;
 }
 
@@ -271,30 +329,33 @@ int scan_fwd_launch(const mm_scan_args* a, hipStream_t stream) {
   p.out = a->out; p.x_chk = a->x_chk;
   p.u_sb = a->u_sb; p.u_sd = a->u_sd; p.d_sb = a->delta_sb; p.d_sd = a->delta_sd;
   p.B_sb = a->B_sb; p.B_sg = a->B_sg; p.B_sn = a->B_sn; p.C_sb = a->C_sb; p.C_sg = a->C_sg; p.C_sn = a->C_sn;
-  p.dim = a->dim; p.L = a->L; p.G = a->G; p.H = a->dim / a->G;
+  p.batch = a->batch; p.dim = a->dim; p.L = a->L; p.G = a->G; p.H = a->dim / a->G;
   p.ntiles = (a->L + kTile - 1) / kTile;
   p.nchk = (a->L + kChunk - 1) / kChunk;
-  p.softplus = a->delta_softplus;
-
-  int ns = a->variant ? a->variant : plan_fwd_variant(a->batch, a->G, p.H, a->L);
+  p.dbg = (a->variant >> 8) & 0xff;
+  int ns = (a->variant & 0xff) ? (a->variant & 0xff) : plan_fwd_variant(a->batch, a->G, p.H, a->L);
   if (ns != 1 && ns != 2 && ns != 4) return MM_ERR_UNSUPPORTED;
+  int wpb = (a->variant >> 16) & 0xff;      // waves per workgroup (tuning knob; waves never synchronise)
+  if (wpb <= 0) wpb = 2;
+  if (wpb > 4) wpb = 4;
   const int CH = 4 * ns;
-  // waves per workgroup: cover the whole group if it fits in 12 waves, else the divisor-friendly split
-  const int waves_needed = (p.H + CH - 1) / CH;
-  int ncw = (waves_needed + 11) / 12;
-  int waves = (waves_needed + ncw - 1) / ncw;
-  p.CW = waves * CH;
-  p.ncw = (p.H + p.CW - 1) / p.CW;
-  const int nblocks = a->batch * a->G * p.ncw;
+  p.wpg = (p.H + CH - 1) / CH;
+  // 32-bit byte offsets inside one batch item must not overflow
+  const int64_t span = (int64_t)a->dim * (a->u_sd > a->L ? a->u_sd : a->L) * 4;
+  if (span >= 0x7ffffff0ll || (int64_t)kNState * a->B_sn * 4 >= 0x7ffffff0ll) return MM_ERR_UNSUPPORTED;
+  p.nwaves_total = a->batch * a->G * p.wpg;
+  int nblocks = (p.nwaves_total + wpb - 1) / wpb;
+  nblocks = (nblocks + 7) & ~7;             // multiple of 8 so the XCD remap is a bijection; surplus waves exit
 
   const bool vec = (a->L % 4 == 0) && aligned16(a->u) && aligned16(a->delta) && aligned16(a->B) && aligned16(a->C) &&
                    aligned16(a->out) && a->u_sb % 4 == 0 && a->u_sd % 4 == 0 && a->delta_sb % 4 == 0 &&
                    a->delta_sd % 4 == 0 && a->B_sb % 4 == 0 && a->B_sg % 4 == 0 && a->B_sn % 4 == 0 &&
                    a->C_sb % 4 == 0 && a->C_sg % 4 == 0 && a->C_sn % 4 == 0;
+  const bool sp = a->delta_softplus != 0;
   switch (ns) {
-    case 1: return launch_vec<1>(p, nblocks, waves, vec, stream);
-    case 2: return launch_vec<2>(p, nblocks, waves, vec, stream);
-    default: return launch_vec<4>(p, nblocks, waves, vec, stream);
+    case 1: return launch_ns<1>(p, nblocks, wpb, vec, sp, stream);
+    case 2: return launch_ns<2>(p, nblocks, wpb, vec, sp, stream);
+    default: return launch_ns<4>(p, nblocks, wpb, vec, sp, stream);
   }
 }
 

@@ -132,7 +132,7 @@ def test_forward_options():
     u, delta, A, B, C, D, bias, dout = base
     _check_fwd((u, delta, A, B, C, None, bias, dout))            # D = None
     _check_fwd((u, delta, A, B, C, D, None, dout))               # no bias
-    _check_fwd((u, delta * 0.1, A, B, C, D, bias, dout), softplus=False)
+    _check_fwd((u, delta.abs() * 0.1, A, B, C, D, bias.abs() * 0.01, dout), softplus=False)   # delta' must stay > 0
     _check_fwd(_make(2, 4, 16, 100, seed=6, contiguous_bc=True))
     # softplus threshold branch (x > 20) and very negative raw delta (log1p series branch)
     d2 = delta.clone(); d2[:, :, ::7] = 25.0; d2[:, :, 3::11] = -30.0
@@ -149,7 +149,7 @@ def test_backward_options():
     u, delta, A, B, C, D, bias, dout = _make(2, 4, 16, 100, seed=8)
     _check_bwd((u, delta, A, B, C, None, bias, dout))
     _check_bwd((u, delta, A, B, C, D, None, dout))
-    _check_bwd((u, delta * 0.1, A, B, C, D, bias, dout), softplus=False)
+    _check_bwd((u, delta.abs() * 0.1, A, B, C, D, bias.abs() * 0.01, dout), softplus=False)
 
 
 def test_full_size_properties_stage1():

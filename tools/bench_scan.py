@@ -39,10 +39,15 @@ def main():
     model = sys.argv[1] if len(sys.argv) > 1 else "S"
     Bz = int(sys.argv[2]) if len(sys.argv) > 2 else 64
     variants = [int(v) for v in sys.argv[3].split(",")] if len(sys.argv) > 3 else [0, 1, 2, 4]
+    stages = [int(v) for v in sys.argv[4].split(",")] if len(sys.argv) > 4 else [0, 1, 2, 3]
+    iters = int(sys.argv[5]) if len(sys.argv) > 5 else 20
+    do_bwd = (sys.argv[6] != "nobwd") if len(sys.argv) > 6 else True
     dev = torch.device("cuda:0")
     K, N = 4, 16
     rows = []
-    for D, L, nblk in STAGES[model]:
+    for si, (D, L, nblk) in enumerate(STAGES[model]):
+        if si not in stages:
+            continue
         R = max(1, (D // 2 + 15) // 16)
         g = torch.Generator(device=dev).manual_seed(0)
         u = torch.randn(Bz, K * D, L, device=dev, generator=g)
@@ -56,7 +61,7 @@ def main():
         bf, bb = bytes_fwd(Bz, K, D, N, L), bytes_bwd(Bz, K, D, N, L)
         for v in variants:
             try:
-                med, mn = timeit(lambda: SelectiveScanFn.apply(u, delta, A, Bs, Cs, Dp, bias, True, v))
+                med, mn = timeit(lambda: SelectiveScanFn.apply(u, delta, A, Bs, Cs, Dp, bias, True, v), iters=iters)
             except Exception as e:  # noqa
                 print(f"D={D} L={L} variant={v}: {e}")
                 continue
@@ -64,6 +69,8 @@ def main():
                        fwd_GBs=bf / med / 1e6, fwd_frac_8TBs=bf / med / 1e6 / 8000)
             rows.append(row)
             print(json.dumps(row), flush=True)
+        if not do_bwd:
+            continue
         # training forward (writes checkpoints) + backward, default variant
         ins = [t.detach().requires_grad_() for t in (u, delta, A, Bs, Cs, Dp, bias)]
         med_f, _ = timeit(lambda: SelectiveScanFn.apply(*ins, True, 0))
@@ -74,8 +81,9 @@ def main():
         rows.append(row)
         print(json.dumps(row), flush=True)
     tot_f = sum(r["fwd_ms"] * r["blocks"] for r in rows if r["variant"] == 0)
-    tot_bytes = sum(bytes_fwd(Bz, K, D, N, L) * n for D, L, n in STAGES[model])
-    print(json.dumps(dict(summary="scan fwd, all blocks of one model forward", model=model, batch=Bz, ms=tot_f,
+    tot_bytes = sum(bytes_fwd(Bz, K, D, N, L) * n for si, (D, L, n) in enumerate(STAGES[model]) if si in stages)
+    if tot_f > 0:
+      print(json.dumps(dict(summary="scan fwd, all blocks of one model forward", model=model, batch=Bz, ms=tot_f,
                           GB=tot_bytes / 1e9, GBs=tot_bytes / tot_f / 1e6, frac_8TBs=tot_bytes / tot_f / 1e6 / 8000)))
     os.makedirs("gpurun_out", exist_ok=True)
     json.dump(rows, open(f"gpurun_out/bench_scan_{model}_{Bz}.json", "w"), indent=1)
