@@ -1,0 +1,171 @@
+#!/usr/bin/env python3
+"""Headline benchmark (BASELINE.json: "images/sec fwd+bwd MedMamba-S 224^2 @1/2/4/8 MI355X; SS2D scan
+HBM GB/s vs roofline").
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+One "step" = one full training step of MedMamba-S (train.py:277-288: zero_grad, forward, CrossEntropy,
+backward, AdamW step) on a synthetic 224x224x3 batch of 64 images per GPU that is already resident in HBM.
+Weak scaling: per-GPU batch fixed, one process per GPU, gradients all-reduced by DistributedDataParallel
+over RCCL (backend "nccl").  Rank 0 prints ONE JSON line.
+
+Extra objects on the line:
+  roofline     — the selective-scan forward kernel (the north-star kernel): algorithmic bytes
+                 of every forward scan call in the timed steps / their hipEvent-measured duration, vs 8 TB/s.
+  roofline_bwd — same for the backward scan kernel.
+  cpu_baseline — the CPU restatement of the reference path (oracle/: torch-CPU glue + C selective_scan_ref)
+                 timed on this box's host cores on a bounded sample (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md §Chip-level parameters)
+
+
+def cpu_baseline(size, res, nimg=2):
+    """fwd+bwd of the same model through the CPU oracle (kind "port"): bounded sample of `nimg` images."""
+    from oracle import model_ref as R
+    from oracle.scan_ref import c_selective_scan_fn, build_c_oracle
+    from medmamba_amd.modules import VSSM, MEDMAMBA_CONFIGS
+    build_c_oracle()
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(42)
+    cfg = MEDMAMBA_CONFIGS[size]
+    net = VSSM(num_classes=6, **cfg)          # CPU copy, only used as a parameter container
+    p = {k: (v.detach().clone().requires_grad_() if v.dtype.is_floating_point and "running" not in k else v.clone())
+         for k, v in net.state_dict().items()}
+    x = torch.randn(nimg, 3, res, res)
+    y = torch.randint(0, 6, (nimg,))
+
+    def step():
+        for v in p.values():
+            if v.requires_grad:
+                v.grad = None
+        loss = nn.functional.cross_entropy(R.vssm_forward(p, x, cfg["depths"], c_selective_scan_fn, training=True), y)
+        loss.backward()
+        return float(loss)
+
+    step()                                     # warm-up (first call is ~3x slower: allocator growth)
+    t0 = time.perf_counter()
+    step()
+    dt = time.perf_counter() - t0
+    return dict(value=nimg / dt, unit="images/s", cores=cores, kind="port",
+                sample=f"{nimg} images, MedMamba-{size} {res}x{res} fwd+bwd (no optimizer step), torch-CPU glue + "
+                       f"oracle/selective_scan_ref.c scan on {cores} threads, 1 warm-up + 1 timed pass "
+                       f"({dt:.1f} s)")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="images per GPU (BASELINE config 3/4: 64)")
+    ap.add_argument("--size", default="S", choices=["T", "S", "B", "Te"])
+    ap.add_argument("--res", type=int, default=224)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (there is no CPU path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)     # "nccl" is RCCL on ROCm
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from medmamba_amd.modules import VSSM, MEDMAMBA_CONFIGS
+    from medmamba_amd.selective_scan_interface import KERNEL_TIMER
+    from medmamba_amd.ddp import wrap_ddp
+
+    torch.manual_seed(42)                      # identical replicas; random-init weights (no checkpoints offline)
+    net = VSSM(num_classes=6, **MEDMAMBA_CONFIGS[args.size]).to(dev).train()
+    model = wrap_ddp(net, dev) if world > 1 else net
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=1e-4)     # train.py:189-192 (ImageFolder branch)
+    loss_fn = nn.CrossEntropyLoss()
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    images = torch.randn(args.batch, 3, args.res, args.res, device=dev, generator=g)   # resident in HBM
+    labels = torch.randint(0, 6, (args.batch,), device=dev, generator=g)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = loss_fn(model(images), labels)
+        loss.backward()
+        opt.step()
+        return loss
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    KERNEL_TIMER.enabled = True
+    KERNEL_TIMER.records.clear()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    KERNEL_TIMER.enabled = False
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert torch.isfinite(loss).item(), "loss is not finite"
+
+    if rank == 0:
+        ks = KERNEL_TIMER.summary()
+
+        def roof(tag):
+            d = ks.get(tag)
+            if not d or d["ms"] <= 0:
+                return None
+            gbs = d["bytes"] / d["ms"] / 1e6
+            return {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "kernel": tag,
+                    "calls": d["calls"], "avg_us_per_call": round(1e3 * d["ms"] / d["calls"], 2),
+                    "algorithmic_MB_per_call": round(d["bytes"] / d["calls"] / 1e6, 2)}
+
+        out = {
+            "metric": "images/sec fwd+bwd MedMamba-S 224^2", "value": round(args.batch * world * args.steps / dt, 2),
+            "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"MedMamba-{args.size} {args.res}x{args.res}x3 training step (fwd + CE loss + bwd + "
+                                   f"AdamW), {args.batch} images per GPU resident in HBM, random-init weights",
+                       "batch_per_gpu": args.batch, "global_batch": args.batch * world,
+                       "parallelism": f"dp{world} (DistributedDataParallel over RCCL)" if world > 1 else "single GPU"},
+            "roofline": roof("scan_fwd"), "roofline_bwd": roof("scan_bwd"),
+            "final_loss": round(float(loss), 5),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.size, args.res)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,328 @@
+"""nn.Module surface of the MedMamba hot path, backed by the gfx950 HIP kernels.
+
+Same constructor arguments, attribute names, forward signatures and state-dict keys/shapes as the
+reference model file, so reference checkpoints load and reference-style callers
+(`net.layers[-1].blocks[-1].conv33conv33conv11[-2]`, test.py:101) keep working:
+
+    PatchEmbed2D      MedMamba.py:54-76        SS2D          MedMamba.py:123-305
+    PatchMerging2D    MedMamba.py:79-119       SS_Conv_SSM   MedMamba.py:322-357
+    channel_shuffle   MedMamba.py:308-320      VSSLayer      MedMamba.py:359-422
+    DropPath / trunc_normal_ (timm.layers, MedMamba.py:11)   VSSM  MedMamba.py:423-515
+
+Parameter initialisation consumes the torch RNG in the same order as the reference constructors
+(incl. the "fake init" of VSSLayer, MedMamba.py:398-404), so `torch.manual_seed(s); VSSM(...)`
+yields the same weights — pinned by tests/golden/kat_seed42.json.
+
+There is no CPU path: the selective scan is `medmamba_amd.selective_scan_fn` (HIP, C ABI).
+"""
+import math
+from functools import partial
+from typing import Callable
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+import torch.utils.checkpoint as checkpoint
+
+from .selective_scan_interface import selective_scan_fn
+
+trunc_normal_ = nn.init.trunc_normal_   # timm.layers.trunc_normal_ == torch.nn.init.trunc_normal_
+
+
+class DropPath(nn.Module):
+    """Per-sample stochastic depth (timm.layers.DropPath semantics; MedMamba.py:335)."""
+
+    def __init__(self, drop_prob: float = 0.0, scale_by_keep: bool = True):
+        super().__init__()
+        self.drop_prob = drop_prob
+        self.scale_by_keep = scale_by_keep
+
+    def forward(self, x):
+        if self.drop_prob == 0.0 or not self.training:
+            return x
+        keep = 1.0 - self.drop_prob
+        mask = x.new_empty((x.shape[0],) + (1,) * (x.ndim - 1)).bernoulli_(keep)
+        if keep > 0.0 and self.scale_by_keep:
+            mask.div_(keep)
+        return x * mask
+
+    def __repr__(self):
+        return f"timm.DropPath({self.drop_prob})"
+
+
+class PatchEmbed2D(nn.Module):
+    """Image -> (B, H/4, W/4, C) patch tokens: strided conv + LayerNorm (MedMamba.py:54-76)."""
+
+    def __init__(self, patch_size=4, in_chans=3, embed_dim=96, norm_layer=None, **kwargs):
+        super().__init__()
+        if isinstance(patch_size, int):
+            patch_size = (patch_size, patch_size)
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size)
+        self.norm = norm_layer(embed_dim) if norm_layer is not None else None
+
+    def forward(self, x):
+        x = self.proj(x).permute(0, 2, 3, 1)
+        return x if self.norm is None else self.norm(x)
+
+
+class PatchMerging2D(nn.Module):
+    """2x2 patch merge: gather -> LayerNorm(4C) -> Linear(4C, 2C) (MedMamba.py:79-119).
+    Odd H/W are cropped to the even part, with the reference's printed warning (MedMamba.py:97-111)."""
+
+    def __init__(self, dim, norm_layer=nn.LayerNorm):
+        super().__init__()
+        self.dim = dim
+        self.reduction = nn.Linear(4 * dim, 2 * dim, bias=False)
+        self.norm = norm_layer(4 * dim)
+
+    def forward(self, x):
+        B, H, W, C = x.shape
+        if (W % 2 != 0) or (H % 2 != 0):
+            print(f"Warning, x.shape {x.shape} is not match even ===========", flush=True)
+        h2, w2 = H // 2, W // 2
+        x = x[:, :2 * h2, :2 * w2, :].reshape(B, h2, 2, w2, 2, C)
+        # reference channel order: (row even, col even), (row odd, col even), (row even, col odd), (row odd, col odd)
+        x = x.permute(0, 1, 3, 4, 2, 5).reshape(B, h2, w2, 4 * C)
+        return self.reduction(self.norm(x))
+
+
+def channel_shuffle(x, groups: int):
+    """(…, g, c/g) -> (…, c/g, g) on the last dim (MedMamba.py:308-320)."""
+    b, h, w, c = x.shape
+    return x.view(b, h, w, groups, c // groups).transpose(3, 4).reshape(b, h, w, c)
+
+
+class SS2D(nn.Module):
+    """2-D selective scan block (MedMamba.py:123-305): in_proj -> depthwise conv3x3 + SiLU ->
+    4-direction scan (cross-scan, x/dt projections, selective scan, cross-merge) -> LayerNorm ->
+    gate with SiLU(z) -> out_proj."""
+
+    def __init__(self, d_model, d_state=16, d_conv=3, expand=2, dt_rank="auto", dt_min=0.001, dt_max=0.1,
+                 dt_init="random", dt_scale=1.0, dt_init_floor=1e-4, dropout=0., conv_bias=True, bias=False,
+                 device=None, dtype=None, **kwargs):
+        fk = {"device": device, "dtype": dtype}
+        super().__init__()
+        self.d_model, self.d_state, self.d_conv, self.expand = d_model, d_state, d_conv, expand
+        self.d_inner = int(expand * d_model)
+        self.dt_rank = math.ceil(d_model / 16) if dt_rank == "auto" else dt_rank
+        K, C = 4, self.dt_rank + 2 * d_state
+
+        self.in_proj = nn.Linear(d_model, 2 * self.d_inner, bias=bias, **fk)
+        self.conv2d = nn.Conv2d(self.d_inner, self.d_inner, groups=self.d_inner, bias=conv_bias, kernel_size=d_conv,
+                                padding=(d_conv - 1) // 2, **fk)
+        self.act = nn.SiLU()
+        # RNG order of the reference: 4 x_proj Linears, then 4 x (dt weight, dt bias rand) — MedMamba.py:164-181
+        xp = [nn.Linear(self.d_inner, C, bias=False, **fk).weight for _ in range(K)]
+        self.x_proj_weight = nn.Parameter(torch.stack(xp, dim=0))                      # (4, R+2N, d_inner)
+        dts = [self.dt_init(self.dt_rank, self.d_inner, dt_scale, dt_init, dt_min, dt_max, dt_init_floor, **fk)
+               for _ in range(K)]
+        self.dt_projs_weight = nn.Parameter(torch.stack([t.weight for t in dts], dim=0))   # (4, d_inner, R)
+        self.dt_projs_bias = nn.Parameter(torch.stack([t.bias for t in dts], dim=0))       # (4, d_inner)
+        self.A_logs = self.A_log_init(d_state, self.d_inner, copies=K, merge=True)         # (4*d_inner, N)
+        self.Ds = self.D_init(self.d_inner, copies=K, merge=True)                          # (4*d_inner,)
+        self.forward_core = self.forward_corev0
+        self.out_norm = nn.LayerNorm(self.d_inner)
+        self.out_proj = nn.Linear(self.d_inner, d_model, bias=bias, **fk)
+        self.dropout = nn.Dropout(dropout) if dropout > 0. else None
+
+    @staticmethod
+    def dt_init(dt_rank, d_inner, dt_scale=1.0, dt_init="random", dt_min=0.001, dt_max=0.1, dt_init_floor=1e-4,
+                **fk):
+        """dt projection whose bias is softplus^-1 of a log-uniform dt in [dt_min, dt_max] (MedMamba.py:193-218)."""
+        proj = nn.Linear(dt_rank, d_inner, bias=True, **fk)
+        std = dt_rank ** -0.5 * dt_scale
+        if dt_init == "constant":
+            nn.init.constant_(proj.weight, std)
+        elif dt_init == "random":
+            nn.init.uniform_(proj.weight, -std, std)
+        else:
+            raise NotImplementedError
+        dt = torch.exp(torch.rand(d_inner, **fk) * (math.log(dt_max) - math.log(dt_min)) + math.log(dt_min))
+        dt = dt.clamp(min=dt_init_floor)
+        with torch.no_grad():
+            proj.bias.copy_(dt + torch.log(-torch.expm1(-dt)))
+        proj.bias._no_reinit = True
+        return proj
+
+    @staticmethod
+    def A_log_init(d_state, d_inner, copies=1, device=None, merge=True):
+        """A = -(1..N) per channel, stored as log (MedMamba.py:220-235)."""
+        a = torch.log(torch.arange(1, d_state + 1, dtype=torch.float32, device=device)).repeat(d_inner, 1)
+        if copies > 1:
+            a = a.unsqueeze(0).repeat(copies, 1, 1)
+            if merge:
+                a = a.flatten(0, 1)
+        p = nn.Parameter(a.contiguous())
+        p._no_weight_decay = True
+        return p
+
+    @staticmethod
+    def D_init(d_inner, copies=1, device=None, merge=True):
+        """Skip parameter D = 1 (MedMamba.py:237-247)."""
+        d = torch.ones(d_inner, device=device)
+        if copies > 1:
+            d = d.unsqueeze(0).repeat(copies, 1)
+            if merge:
+                d = d.flatten(0, 1)
+        p = nn.Parameter(d)
+        p._no_weight_decay = True
+        return p
+
+    def forward_corev0(self, x):
+        """x (B, D, H, W) -> the four un-flipped / un-transposed direction outputs (MedMamba.py:249-286)."""
+        self.selective_scan = selective_scan_fn
+        B, _, H, W = x.shape
+        L, K = H * W, 4
+        x_hwwh = torch.stack([x.view(B, -1, L), x.transpose(2, 3).contiguous().view(B, -1, L)], dim=1)
+        xs = torch.cat([x_hwwh, x_hwwh.flip(-1)], dim=1)                                   # (B, 4, D, L)
+        x_dbl = torch.einsum("bkdl,kcd->bkcl", xs, self.x_proj_weight)
+        dts, Bs, Cs = torch.split(x_dbl, [self.dt_rank, self.d_state, self.d_state], dim=2)
+        dts = torch.einsum("bkrl,kdr->bkdl", dts, self.dt_projs_weight)
+        out_y = self.selective_scan(
+            xs.float().view(B, -1, L), dts.contiguous().float().view(B, -1, L),
+            -torch.exp(self.A_logs.float()).view(-1, self.d_state), Bs.float(), Cs.float(),
+            self.Ds.float().view(-1), z=None, delta_bias=self.dt_projs_bias.float().view(-1),
+            delta_softplus=True, return_last_state=False).view(B, K, -1, L)
+        assert out_y.dtype == torch.float
+        inv_y = out_y[:, 2:4].flip(-1)
+        wh_y = out_y[:, 1].view(B, -1, W, H).transpose(2, 3).contiguous().view(B, -1, L)
+        invwh_y = inv_y[:, 1].view(B, -1, W, H).transpose(2, 3).contiguous().view(B, -1, L)
+        return out_y[:, 0], inv_y[:, 0], wh_y, invwh_y
+
+    def forward(self, x, **kwargs):
+        B, H, W, _ = x.shape
+        x, z = self.in_proj(x).chunk(2, dim=-1)
+        x = self.act(self.conv2d(x.permute(0, 3, 1, 2).contiguous()))
+        y1, y2, y3, y4 = self.forward_core(x)
+        assert y1.dtype == torch.float32
+        y = (y1 + y2 + y3 + y4).transpose(1, 2).contiguous().view(B, H, W, -1)
+        out = self.out_proj(self.out_norm(y) * F.silu(z))
+        return out if self.dropout is None else self.dropout(out)
+
+
+class SS_Conv_SSM(nn.Module):
+    """One MedMamba block (MedMamba.py:322-357): channel halves -> {conv branch | LayerNorm + SS2D} ->
+    concat -> channel shuffle -> residual."""
+
+    def __init__(self, hidden_dim: int = 0, drop_path: float = 0,
+                 norm_layer: Callable[..., nn.Module] = partial(nn.LayerNorm, eps=1e-6),
+                 attn_drop_rate: float = 0, d_state: int = 16, **kwargs):
+        super().__init__()
+        half = hidden_dim // 2
+        self.ln_1 = norm_layer(half)
+        self.self_attention = SS2D(d_model=half, dropout=attn_drop_rate, d_state=d_state, **kwargs)
+        self.drop_path = DropPath(drop_path)
+        self.conv33conv33conv11 = nn.Sequential(
+            nn.BatchNorm2d(half),
+            nn.Conv2d(half, half, kernel_size=3, stride=1, padding=1),
+            nn.BatchNorm2d(half),
+            nn.ReLU(),
+            nn.Conv2d(half, half, kernel_size=3, stride=1, padding=1),
+            nn.BatchNorm2d(half),
+            nn.ReLU(),
+            nn.Conv2d(half, half, kernel_size=1, stride=1),
+            nn.ReLU(),
+        )
+
+    def forward(self, input):
+        left, right = input.chunk(2, dim=-1)
+        x = self.drop_path(self.self_attention(self.ln_1(right)))
+        left = self.conv33conv33conv11(left.permute(0, 3, 1, 2).contiguous()).permute(0, 2, 3, 1).contiguous()
+        return channel_shuffle(torch.cat((left, x), dim=-1), groups=2) + input
+
+
+class VSSLayer(nn.Module):
+    """One stage: `depth` blocks then an optional downsample (MedMamba.py:359-422)."""
+
+    def __init__(self, dim, depth, attn_drop=0., drop_path=0., norm_layer=nn.LayerNorm, downsample=None,
+                 use_checkpoint=False, d_state=16, **kwargs):
+        super().__init__()
+        self.dim = dim
+        self.use_checkpoint = use_checkpoint
+        self.blocks = nn.ModuleList([
+            SS_Conv_SSM(hidden_dim=dim, drop_path=drop_path[i] if isinstance(drop_path, list) else drop_path,
+                        norm_layer=norm_layer, attn_drop_rate=attn_drop, d_state=d_state)
+            for i in range(depth)])
+        # The reference draws (and discards) a kaiming-uniform sample per out_proj.weight here, once per
+        # module that owns one under that name (MedMamba.py:398-404).  Only the RNG stream matters.
+        for m in self.modules():
+            for name, p in m.named_parameters():
+                if name == "out_proj.weight":
+                    nn.init.kaiming_uniform_(p.clone().detach_(), a=math.sqrt(5))
+        self.downsample = downsample(dim=dim, norm_layer=norm_layer) if downsample is not None else None
+
+    def forward(self, x):
+        for blk in self.blocks:
+            x = checkpoint.checkpoint(blk, x) if self.use_checkpoint else blk(x)
+        return x if self.downsample is None else self.downsample(x)
+
+
+class VSSM(nn.Module):
+    """MedMamba classifier (MedMamba.py:423-515). T/S/B/Te are just depths/dims (train.py:179-182)."""
+
+    def __init__(self, patch_size=4, in_chans=3, num_classes=1000, depths=[2, 2, 4, 2], dims=[96, 192, 384, 768],
+                 d_state=16, drop_rate=0., attn_drop_rate=0., drop_path_rate=0.1, norm_layer=nn.LayerNorm,
+                 patch_norm=True, use_checkpoint=False, **kwargs):
+        super().__init__()
+        self.num_classes = num_classes
+        self.num_layers = len(depths)
+        if isinstance(dims, int):
+            dims = [int(dims * 2 ** i) for i in range(self.num_layers)]
+        self.embed_dim, self.num_features, self.dims = dims[0], dims[-1], dims
+        self.patch_embed = PatchEmbed2D(patch_size=patch_size, in_chans=in_chans, embed_dim=self.embed_dim,
+                                        norm_layer=norm_layer if patch_norm else None)
+        self.ape = False
+        self.pos_drop = nn.Dropout(p=drop_rate)
+        dpr = [x.item() for x in torch.linspace(0, drop_path_rate, sum(depths))]
+        self.layers = nn.ModuleList()
+        for i in range(self.num_layers):
+            self.layers.append(VSSLayer(
+                dim=dims[i], depth=depths[i], d_state=math.ceil(dims[0] / 6) if d_state is None else d_state,
+                drop=drop_rate, attn_drop=attn_drop_rate, drop_path=dpr[sum(depths[:i]):sum(depths[:i + 1])],
+                norm_layer=norm_layer, downsample=PatchMerging2D if i < self.num_layers - 1 else None,
+                use_checkpoint=use_checkpoint))
+        self.avgpool = nn.AdaptiveAvgPool2d(1)
+        self.head = nn.Linear(self.num_features, num_classes) if num_classes > 0 else nn.Identity()
+        self.apply(self._init_weights)
+        for m in self.modules():                      # MedMamba.py:471-473 (every Conv2d, incl. depthwise)
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+
+    def _init_weights(self, m):
+        if isinstance(m, nn.Linear):
+            trunc_normal_(m.weight, std=.02)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
+
+    @torch.jit.ignore
+    def no_weight_decay(self):
+        return {'absolute_pos_embed'}
+
+    @torch.jit.ignore
+    def no_weight_decay_keywords(self):
+        return {'relative_position_bias_table'}
+
+    def forward_backbone(self, x):
+        x = self.pos_drop(self.patch_embed(x))
+        for layer in self.layers:
+            x = layer(x)
+        return x
+
+    def forward(self, x):
+        x = self.forward_backbone(x).permute(0, 3, 1, 2)
+        return self.head(torch.flatten(self.avgpool(x), start_dim=1))
+
+
+MEDMAMBA_CONFIGS = {   # train.py:179-182
+    "T": dict(depths=[2, 2, 4, 2], dims=[96, 192, 384, 768]),
+    "S": dict(depths=[2, 2, 8, 2], dims=[96, 192, 384, 768]),
+    "B": dict(depths=[2, 2, 12, 2], dims=[128, 256, 512, 1024]),
+    "Te": dict(depths=[2, 3, 3, 2], dims=[96, 192, 384, 768]),
+}
+
+
+def medmamba(size="T", num_classes=6, **kwargs):
+    return VSSM(num_classes=num_classes, **MEDMAMBA_CONFIGS[size], **kwargs)

@@ -16,6 +16,55 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
+class _KernelTimer:
+    """Optional hipEvent bracket around every kernel launch (used by bench.py for the roofline figures).
+    Events are recorded on torch's current stream, which is the stream the kernels are launched on;
+    recording is asynchronous, elapsed times are read after the caller has synchronised."""
+
+    def __init__(self):
+        self.enabled = False
+        self.records = []          # (tag, start_event, end_event, algorithmic_bytes)
+
+    def start(self):
+        if not self.enabled:
+            return None
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        return ev
+
+    def stop(self, tag, start, nbytes):
+        if start is None:
+            return
+        end = torch.cuda.Event(enable_timing=True)
+        end.record()
+        self.records.append((tag, start, end, nbytes))
+
+    def summary(self):
+        """{tag: dict(calls, ms, bytes)} — call only after torch.cuda.synchronize()."""
+        out = {}
+        for tag, s, e, nb in self.records:
+            d = out.setdefault(tag, dict(calls=0, ms=0.0, bytes=0))
+            d["calls"] += 1
+            d["ms"] += s.elapsed_time(e)
+            d["bytes"] += nb
+        return out
+
+
+KERNEL_TIMER = _KernelTimer()
+
+
+def scan_bytes_fwd(batch, dim, L, N, G):
+    """Algorithmic bytes of one forward call at the operator boundary (SURVEY §8d): read u, delta; write out;
+    read B, C; A, D, delta_bias once."""
+    return 4 * batch * L * (3 * dim + 2 * G * N) + 4 * (dim * N + 2 * dim)
+
+
+def scan_bytes_bwd(batch, dim, L, N, G):
+    """Algorithmic bytes of one backward call (SURVEY §8d): read u, delta, dout; write du, ddelta; read B, C;
+    write dB, dC; parameters + parameter gradients."""
+    return 4 * batch * L * (5 * dim + 4 * G * N) + 8 * (dim * N + 2 * dim)
+
+
 def _check_inputs(u, delta, A, B, C, D, z, delta_bias, return_last_state):
     if z is not None:
         raise NotImplementedError("z gating is not on the MedMamba path (MedMamba.py:275 passes z=None)")
@@ -85,7 +134,9 @@ class SelectiveScanFn(torch.autograd.Function):
         _fill_common(a, u, delta, A, B, C, D, delta_bias, delta_softplus)
         a.out, a.x_chk, a.variant = out.data_ptr(), _ptr(x_chk), int(variant)
         with torch.cuda.device(u.device):
+            t0 = KERNEL_TIMER.start()
             rc = _lib.lib().mm_scan_fwd(a, torch.cuda.current_stream().cuda_stream)
+            KERNEL_TIMER.stop("scan_fwd", t0, scan_bytes_fwd(batch, dim, L, A.shape[1], B.shape[1]))
         _lib.check(rc, "mm_scan_fwd")
         if need_grad:
             ctx.save_for_backward(u, delta, A, B, C, D, delta_bias, x_chk)
@@ -113,7 +164,9 @@ class SelectiveScanFn(torch.autograd.Function):
                                             dC.data_ptr())
         a.dD, a.ddelta_bias = _ptr(dD), _ptr(dbias)
         with torch.cuda.device(dev):
+            t0 = KERNEL_TIMER.start()
             rc = _lib.lib().mm_scan_bwd(a, torch.cuda.current_stream().cuda_stream)
+            KERNEL_TIMER.stop("scan_bwd", t0, scan_bytes_bwd(batch, dim, L, N, G))
         _lib.check(rc, "mm_scan_bwd")
         return du, ddelta, dA, dB, dC, dD, dbias, None, None
 

@@ -1,0 +1,74 @@
+"""CPU, world_size 2, gloo: the data-parallel wrapper averages gradients across ranks exactly like a
+single-process run on the concatenated batch does for batch-independent parameters.  The scan inside the
+model is the oracle injected by the TEST in each worker (no GPU here)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _build_model():
+    from medmamba_amd import modules as M
+    from oracle.scan_ref import c_selective_scan_fn
+    M.selective_scan_fn = c_selective_scan_fn          # test double; the product has no CPU scan
+    torch.manual_seed(7)
+    net = M.VSSM(num_classes=3, depths=[1, 1], dims=[16, 32], drop_path_rate=0.0)
+    net.eval()       # BatchNorm uses running stats -> per-sample independence -> DDP mean == big-batch gradient
+    return net
+
+
+def _worker(rank, world, port, outdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    from medmamba_amd.ddp import init_distributed, wrap_ddp
+    assert init_distributed("gloo") == world
+    net = _build_model()
+    if rank == 1:                      # prove the initial broadcast: perturb rank 1's copy before wrapping
+        with torch.no_grad():
+            for p in net.parameters():
+                p.add_(1.0)
+    model = wrap_ddp(net)
+    g = torch.Generator().manual_seed(100)
+    x = torch.randn(4, 3, 16, 16, generator=g)[2 * rank:2 * rank + 2]
+    y = torch.tensor([0, 1, 2, 1])[2 * rank:2 * rank + 2]
+    loss = torch.nn.functional.cross_entropy(model(x), y)
+    loss.backward()
+    grads = {k: p.grad.clone() for k, p in net.named_parameters()}
+    torch.save(dict(grads=grads, loss=float(loss)), os.path.join(outdir, f"r{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ddp_gradients_match_single_process(tmp_path):
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0 = torch.load(tmp_path / "r0.pt")
+    r1 = torch.load(tmp_path / "r1.pt")
+    for k in r0["grads"]:
+        assert torch.equal(r0["grads"][k], r1["grads"][k]), k          # all-reduced: identical on both ranks
+    net = _build_model()
+    g = torch.Generator().manual_seed(100)
+    x = torch.randn(4, 3, 16, 16, generator=g)
+    y = torch.tensor([0, 1, 2, 1])
+    torch.nn.functional.cross_entropy(net(x), y).backward()           # mean over 4 == mean of the two rank means
+    for k, p in net.named_parameters():
+        w = p.grad
+        err = (r0["grads"][k] - w).abs().max().item()
+        assert err <= 1e-5 * max(1.0, w.abs().max().item()), (k, err)
+
+
+def test_wrap_is_identity_without_process_group():
+    from medmamba_amd.ddp import wrap_ddp
+    m = torch.nn.Linear(2, 2)
+    assert wrap_ddp(m) is m
