@@ -35,14 +35,17 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md §Chip-level parameters)
 
 
-def cpu_baseline(size, res, nimg=2):
+def cpu_baseline(size, res, nimg=32):
     """fwd+bwd of the same model through the CPU oracle (kind "port"): bounded sample of `nimg` images."""
     from oracle import model_ref as R
     from oracle.scan_ref import c_selective_scan_fn, build_c_oracle
     from medmamba_amd.modules import VSSM, MEDMAMBA_CONFIGS
     build_c_oracle()
-    cores = os.cpu_count() or 1
+    # the box's CPU share for one GPU is 16 cores; more threads than that only oversubscribes (256-CPU hosts)
+    cores = max(1, min(16, len(os.sched_getaffinity(0))))
     torch.set_num_threads(cores)
+    from oracle.scan_ref import _lib as _olib
+    _olib().oracle_set_threads(cores)
     torch.manual_seed(42)
     cfg = MEDMAMBA_CONFIGS[size]
     net = VSSM(num_classes=6, **cfg)          # CPU copy, only used as a parameter container
@@ -57,7 +60,7 @@ def cpu_baseline(size, res, nimg=2):
                 v.grad = None
         loss = nn.functional.cross_entropy(R.vssm_forward(p, x, cfg["depths"], c_selective_scan_fn, training=True), y)
         loss.backward()
-        return float(loss)
+        return float(loss.detach())
 
     step()                                     # warm-up (first call is ~3x slower: allocator growth)
     t0 = time.perf_counter()
@@ -67,6 +70,22 @@ def cpu_baseline(size, res, nimg=2):
                 sample=f"{nimg} images, MedMamba-{size} {res}x{res} fwd+bwd (no optimizer step), torch-CPU glue + "
                        f"oracle/selective_scan_ref.c scan on {cores} threads, 1 warm-up + 1 timed pass "
                        f"({dt:.1f} s)")
+
+
+def cpu_baseline_subprocess(size, res, timeout_s=240):
+    """Run the CPU leg in a child process (own thread pools, hard time bound); never blocks the GPU result."""
+    import subprocess
+    code = ("import json,sys; sys.path.insert(0, %r); import bench; "
+            "print('CPUBASE ' + json.dumps(bench.cpu_baseline(%r, %d)))" % (ROOT, size, res))
+    env = dict(os.environ, OMP_NUM_THREADS="16", MKL_NUM_THREADS="16", HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
+    try:
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=timeout_s, env=env)
+        for line in r.stdout.splitlines():
+            if line.startswith("CPUBASE "):
+                return json.loads(line[8:])
+        return dict(value=None, unit="images/s", cores=0, kind="port", sample="cpu leg failed: " + r.stderr[-200:])
+    except subprocess.TimeoutExpired:
+        return dict(value=None, unit="images/s", cores=0, kind="port", sample=f"cpu leg exceeded {timeout_s} s")
 
 
 def main():
@@ -158,10 +177,10 @@ def main():
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                        "parallelism": f"dp{world} (DistributedDataParallel over RCCL)" if world > 1 else "single GPU"},
             "roofline": roof("scan_fwd"), "roofline_bwd": roof("scan_bwd"),
-            "final_loss": round(float(loss), 5),
+            "final_loss": round(float(loss.detach()), 5),
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.size, args.res)
+            out["cpu_baseline"] = cpu_baseline_subprocess(args.size, args.res)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
