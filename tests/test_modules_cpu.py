@@ -114,3 +114,25 @@ def test_models_refuse_cpu_forward_without_injection():
     m = M.SS2D(d_model=8)
     with pytest.raises(RuntimeError, match="HIP device"):
         m(torch.randn(1, 4, 4, 8))
+
+
+def test_compat_registers_the_modules_the_reference_imports():
+    import importlib
+    import sys
+    import medmamba_amd
+    import medmamba_amd.compat as compat
+    compat.install()
+    ssi = importlib.import_module("mamba_ssm.ops.selective_scan_interface")
+    assert ssi.selective_scan_fn is medmamba_amd.selective_scan_fn
+    from timm.layers import DropPath, trunc_normal_     # noqa: F401
+    assert DropPath is M.DropPath
+    ref = "/root/reference"
+    if os.path.isdir(ref):      # build container only: the unchanged reference file imports and builds
+        sys.path.insert(0, ref)
+        try:
+            mod = importlib.import_module("MedMamba")
+            net = mod.VSSM(num_classes=3, depths=[1, 1], dims=[16, 32])
+            assert list(net.state_dict().keys()) == list(
+                M.VSSM(num_classes=3, depths=[1, 1], dims=[16, 32]).state_dict().keys())
+        finally:
+            sys.path.remove(ref)
