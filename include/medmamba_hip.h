@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MM_ABI_VERSION 1
+#define MM_ABI_VERSION 2
 
 enum mm_status {
   MM_OK = 0,
@@ -83,9 +83,20 @@ typedef struct mm_scan_args {
   float* dC;
   float* dD;
   float* ddelta_bias;
-  /* tuning override: 0 = library default; otherwise states-per-lane variant (1,2,4,8,16) */
+  /* tuning override: 0 = library default; low byte = states-per-lane variant (1,2,4) */
   int32_t variant;
-  int32_t reserved;
+  /* Cross-scan without materialising it (replaces the stack/transpose/flip/cat of MedMamba.py:256-257 and the
+   * flips of :282).  All zero = plain selective_scan_fn semantics.
+   *   u_groups : 0 or G -> u holds one channel block per group, shape (batch, G*H, L).  Otherwise u (and dout in
+   *              the backward) hold only u_groups blocks, shape (batch, u_groups*H, L), and group g reads block
+   *              (u_map >> 4*g) & 15   (SS2D: 2 blocks = row-major and column-major image, 4 directions).
+   *   rev_mask : bit g set -> group g runs over the sequence BACKWARDS: its time step t is memory position L-1-t in
+   *              u, delta, B, C, dout and in every per-position output (out, du, ddelta, dB, dC); every tensor stays
+   *              in position order and no flipped copy ever exists.
+   * du is always written per group (batch, G*H, L): the caller sums the groups that share a block. */
+  int32_t u_groups;
+  uint32_t u_map;
+  uint32_t rev_mask;
 } mm_scan_args;
 
 /* replaces selective_scan_cuda.fwd behind selective_scan_fn (MedMamba.py:273-279) */

@@ -25,7 +25,8 @@ class ScanArgs(ctypes.Structure):
         ("C_sb", ctypes.c_int64), ("C_sg", ctypes.c_int64), ("C_sn", ctypes.c_int64),
         ("dout", _f32p), ("du", _f32p), ("ddelta", _f32p), ("dA", _f32p), ("dB", _f32p), ("dC", _f32p),
         ("dD", _f32p), ("ddelta_bias", _f32p),
-        ("variant", ctypes.c_int32), ("reserved", ctypes.c_int32),
+        ("variant", ctypes.c_int32), ("u_groups", ctypes.c_int32), ("u_map", ctypes.c_uint32),
+        ("rev_mask", ctypes.c_uint32),
     ]
 
 
@@ -60,7 +61,7 @@ def lib():
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(handle, name)      # AttributeError if the .so is stale
             fn.restype, fn.argtypes = res, args
-        if handle.mm_abi_version() != 1:
+        if handle.mm_abi_version() != 2:
             raise MedMambaHipError("libmedmamba_hip.so ABI version mismatch; rebuild")
         _lib = handle
     return _lib

@@ -17,6 +17,12 @@ int check_common(const mm_scan_args* a) {
   if (a->dim % a->G != 0) return MM_ERR_SHAPE;
   if (a->N != mm::kNState) return MM_ERR_UNSUPPORTED;   // d_state = 16 on every MedMamba path (MedMamba.py:329,457)
   if (!a->u || !a->delta || !a->A || !a->B || !a->C) return MM_ERR_NULL;
+  if (a->u_groups < 0) return MM_ERR_SHAPE;
+  if (a->u_groups > 0 && a->u_groups < a->G) {
+    if (a->G > 8) return MM_ERR_SHAPE;
+    for (int g = 0; g < a->G; ++g)
+      if ((int)((a->u_map >> (4 * g)) & 15) >= a->u_groups) return MM_ERR_SHAPE;
+  }
   if (!al4(a->u) || !al4(a->delta) || !al4(a->A) || !al4(a->B) || !al4(a->C)) return MM_ERR_ALIGN;
   return MM_OK;
 }

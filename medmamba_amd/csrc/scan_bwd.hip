@@ -38,30 +38,35 @@ struct BwdParams {
   float* __restrict__ dbias;
   int64_t u_sb, u_sd, d_sb, d_sd, B_sb, B_sg, B_sn, C_sb, C_sg, C_sn;
   int dim, L, G, H, CW, ncw, ntiles, nchk, softplus;
+  int ug;                   // channel blocks in u / dout
+  unsigned u_map, rev_mask; // block of group g = (u_map >> 4g) & 15; bit g of rev_mask: group g runs backwards
 };
 
+// Time-ordered quad (time slots t..t+3) of the row at `row`; rev: slot t is memory position L-1-t.
 template <bool VEC>
-__device__ __forceinline__ float4 load4(const float* __restrict__ p, int t, int L) {
+__device__ __forceinline__ float4 load4(const float* __restrict__ row, int t, int L, bool rev = false) {
   if constexpr (VEC) {
-    return t < L ? *reinterpret_cast<const float4*>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (t >= L) return make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 v = *reinterpret_cast<const float4*>(row + (rev ? L - 4 - t : t));
+    return rev ? make_float4(v.w, v.z, v.y, v.x) : v;
   } else {
     float4 v;
-    v.x = t + 0 < L ? p[0] : 0.f;
-    v.y = t + 1 < L ? p[1] : 0.f;
-    v.z = t + 2 < L ? p[2] : 0.f;
-    v.w = t + 3 < L ? p[3] : 0.f;
+    v.x = t + 0 < L ? row[rev ? L - 1 - t : t] : 0.f;
+    v.y = t + 1 < L ? row[rev ? L - 2 - t : t + 1] : 0.f;
+    v.z = t + 2 < L ? row[rev ? L - 3 - t : t + 2] : 0.f;
+    v.w = t + 3 < L ? row[rev ? L - 4 - t : t + 3] : 0.f;
     return v;
   }
 }
 template <bool VEC>
-__device__ __forceinline__ void store4(float* __restrict__ p, int t, int L, float4 v) {
+__device__ __forceinline__ void store4(float* __restrict__ row, int t, int L, float4 v, bool rev = false) {
   if constexpr (VEC) {
-    if (t < L) *reinterpret_cast<float4*>(p) = v;
+    if (t < L) *reinterpret_cast<float4*>(row + (rev ? L - 4 - t : t)) = rev ? make_float4(v.w, v.z, v.y, v.x) : v;
   } else {
-    if (t + 0 < L) p[0] = v.x;
-    if (t + 1 < L) p[1] = v.y;
-    if (t + 2 < L) p[2] = v.z;
-    if (t + 3 < L) p[3] = v.w;
+    if (t + 0 < L) row[rev ? L - 1 - t : t] = v.x;
+    if (t + 1 < L) row[rev ? L - 2 - t : t + 1] = v.y;
+    if (t + 2 < L) row[rev ? L - 3 - t : t + 2] = v.z;
+    if (t + 3 < L) row[rev ? L - 4 - t : t + 3] = v.w;
   }
 }
 __device__ __forceinline__ float f4get(const float4& v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
@@ -77,6 +82,8 @@ __global__ __launch_bounds__(512) void scan_bwd_kernel(const BwdParams p) {
   const int cw = blockIdx.x % p.ncw;
   const int bk = blockIdx.x / p.ncw;
   const int grp = bk % p.G, b = bk / p.G;
+  const int ugrp = p.ug < p.G ? (int)((p.u_map >> (4 * grp)) & 15) : grp;
+  const bool rev = grp < 32 && ((p.rev_mask >> grp) & 1);
 
   float* sBC = smem;                                   // [2][16][kTileStride]   B, C tile
   float* sAcc = smem + 2 * kNState * kTileStride;      // [2][16][kTileStride]   dB, dC accumulators
@@ -102,7 +109,7 @@ __global__ __launch_bounds__(512) void scan_bwd_kernel(const BwdParams p) {
 
   // ---- staging identity
   const int r = lane >> 4, q = lane & 15;
-  int64_t uoff[NLD], doff[NLD], ooff[NLD];
+  int64_t uoff[NLD], doff[NLD], ooff[NLD], goff[NLD];
   float bv[NLD], dDacc[NLD], dbacc[NLD];
   bool rvalid[NLD];
 #pragma unroll
@@ -110,9 +117,11 @@ __global__ __launch_bounds__(512) void scan_bwd_kernel(const BwdParams p) {
     const int hcc = cw * p.CW + wave * CH + 4 * i + r;
     rvalid[i] = hcc < p.H;
     const int dd = grp * p.H + (rvalid[i] ? hcc : 0);
-    uoff[i] = b * p.u_sb + dd * p.u_sd;
+    const int ddu = ugrp * p.H + (rvalid[i] ? hcc : 0);          // channel inside the shared u / dout blocks
+    uoff[i] = b * p.u_sb + ddu * p.u_sd;
     doff[i] = b * p.d_sb + dd * p.d_sd;
     ooff[i] = ((int64_t)b * p.dim + dd) * p.L;
+    goff[i] = ((int64_t)b * p.ug * p.H + ddu) * p.L;
     bv[i] = p.bias ? p.bias[dd] : 0.f;
     dDacc[i] = 0.f;
     dbacc[i] = 0.f;
@@ -131,9 +140,9 @@ __global__ __launch_bounds__(512) void scan_bwd_kernel(const BwdParams p) {
       const int t = t0 + 4 * q;
       const bool ok = rvalid[i];
       const float4 zu = make_float4(0.f, 0.f, 0.f, 0.f);
-      const float4 vu = ok ? load4<VEC>(p.u + uoff[i] + t, t, p.L) : zu;
-      const float4 vd = ok ? load4<VEC>(p.delta + doff[i] + t, t, p.L) : zu;
-      const float4 vg = ok ? load4<VEC>(p.dout + ooff[i] + t, t, p.L) : zu;
+      const float4 vu = ok ? load4<VEC>(p.u + uoff[i], t, p.L, rev) : zu;
+      const float4 vd = ok ? load4<VEC>(p.delta + doff[i], t, p.L, rev) : zu;
+      const float4 vg = ok ? load4<VEC>(p.dout + goff[i], t, p.L, rev) : zu;
       float4 dl;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -153,7 +162,7 @@ __global__ __launch_bounds__(512) void scan_bwd_kernel(const BwdParams p) {
       const int which = idx >> 8, n = (idx >> 4) & 15, qq = idx & 15;
       const float* src = which ? Cbase + n * p.C_sn : Bbase + n * p.B_sn;
       const int o = (which * kNState + n) * kTileStride + 4 * qq;
-      *reinterpret_cast<float4*>(sBC + o) = load4<VEC>(src + t0 + 4 * qq, t0 + 4 * qq, p.L);
+      *reinterpret_cast<float4*>(sBC + o) = load4<VEC>(src, t0 + 4 * qq, p.L, rev);
       *reinterpret_cast<float4*>(sAcc + o) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();
@@ -263,8 +272,8 @@ __global__ __launch_bounds__(512) void scan_bwd_kernel(const BwdParams p) {
       float4 vdd = *reinterpret_cast<const float4*>(s_dl + off);
       vdd.x *= sig[i].x; vdd.y *= sig[i].y; vdd.z *= sig[i].z; vdd.w *= sig[i].w;
       if (rvalid[i]) {
-        store4<VEC>(p.du + ooff[i] + t, t, p.L, vdu);
-        store4<VEC>(p.ddelta + ooff[i] + t, t, p.L, vdd);
+        store4<VEC>(p.du + ooff[i], t, p.L, vdu, rev);
+        store4<VEC>(p.ddelta + ooff[i], t, p.L, vdd, rev);
 #pragma unroll
         for (int e = 0; e < 4; ++e) dbacc[i] += (t + e < p.L) ? f4get(vdd, e) : 0.f;
       }
@@ -272,14 +281,14 @@ __global__ __launch_bounds__(512) void scan_bwd_kernel(const BwdParams p) {
     for (int idx = tid; idx < 512; idx += nthreads) {
       const int which = idx >> 8, n = (idx >> 4) & 15, qq = idx & 15;
       const float4 v = *reinterpret_cast<const float4*>(sAcc + (which * kNState + n) * kTileStride + 4 * qq);
-      float* dst = (which ? dCbase : dBbase) + (int64_t)n * p.L + t0 + 4 * qq;
+      float* dst = (which ? dCbase : dBbase) + (int64_t)n * p.L;
       const int t = t0 + 4 * qq;
       if (p.ncw == 1) {
-        store4<VEC>(dst, t, p.L, v);
+        store4<VEC>(dst, t, p.L, v, rev);
       } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-          if (t + e < p.L) atomicAdd(dst + e, f4get(v, e));
+          if (t + e < p.L) atomicAdd(dst + (rev ? p.L - 1 - t - e : t + e), f4get(v, e));
       }
     }
     __syncthreads();
@@ -318,6 +327,10 @@ int scan_bwd_launch(const mm_scan_args* a, hipStream_t stream) {
   p.ntiles = (a->L + kTile - 1) / kTile;
   p.nchk = (a->L + kChunk - 1) / kChunk;
   p.softplus = a->delta_softplus;
+  const bool shared = a->u_groups > 0 && a->u_groups < a->G;
+  p.ug = shared ? a->u_groups : a->G;
+  p.u_map = shared ? a->u_map : 0x76543210u;
+  p.rev_mask = a->rev_mask;
   const int waves_needed = (p.H + CH - 1) / CH;
   const int ncw0 = (waves_needed + 7) / 8;                   // <= 8 waves (~122 KB LDS) per workgroup
   const int waves = (waves_needed + ncw0 - 1) / ncw0;

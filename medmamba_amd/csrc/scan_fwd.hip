@@ -40,6 +40,8 @@ struct FwdParams {
   int64_t u_sb, u_sd, d_sb, d_sd, B_sb, B_sg, B_sn, C_sb, C_sg, C_sn;
   int batch, dim, L, G, H;  // H = channels per group
   int wpg;                  // waves per (batch, group)
+  int ug;                   // channel blocks in u
+  unsigned u_map, rev_mask; // block of group g = (u_map >> 4g) & 15; bit g of rev_mask: group g runs backwards
   int ntiles, nchk;
   int nwaves_total;
   int dbg;   // timing-only ablation bits (bench diagnostics; results are wrong when set): 1 no y store, 2 no recurrence
@@ -57,23 +59,46 @@ __device__ __forceinline__ rsrc_t make_rsrc(const void* base, int64_t bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)capped, 0x00020000);
 }
 
+// Time-ordered values of time slots t..t+3 of the row that starts at byte offset `row` of descriptor r.
+// rev: slot t lives at memory position L-1-t (the row is walked backwards; nothing is ever flipped in memory).
+// VEC (L % 4 == 0, 16-B aligned rows): one dwordx4, a quad is entirely inside or outside the row.
 template <bool VEC>
-__device__ __forceinline__ float4 bload4(rsrc_t r, int byte_off, bool ok) {
-  // byte_off addresses 4 consecutive floats; VEC: one dwordx4 (row starts are 16-B aligned and L % 4 == 0, so
-  // a quad is entirely in or entirely out of the row); otherwise 4 dword loads with a per-element check.
+__device__ __forceinline__ float4 load_quad(rsrc_t r, int row, int t, int L, bool rev, bool rowok) {
   if constexpr (VEC) {
-    const v4u v = __builtin_amdgcn_raw_buffer_load_b128(r, ok ? byte_off : kOOB, 0, 0);
+    const bool ok = rowok && t < L;
+    const int pos = rev ? L - 4 - t : t;
+    const v4u v = __builtin_amdgcn_raw_buffer_load_b128(r, ok ? row + pos * 4 : kOOB, 0, 0);
     const v4f f = __builtin_bit_cast(v4f, v);
-    return make_float4(f.x, f.y, f.z, f.w);
+    return rev ? make_float4(f.w, f.z, f.y, f.x) : make_float4(f.x, f.y, f.z, f.w);
   } else {
-    float4 o;
-    const unsigned a0 = __builtin_amdgcn_raw_buffer_load_b32(r, ok ? byte_off : kOOB, 0, 0);
-    const unsigned a1 = __builtin_amdgcn_raw_buffer_load_b32(r, ok ? byte_off + 4 : kOOB, 0, 0);
-    const unsigned a2 = __builtin_amdgcn_raw_buffer_load_b32(r, ok ? byte_off + 8 : kOOB, 0, 0);
-    const unsigned a3 = __builtin_amdgcn_raw_buffer_load_b32(r, ok ? byte_off + 12 : kOOB, 0, 0);
-    o.x = __builtin_bit_cast(float, a0); o.y = __builtin_bit_cast(float, a1);
-    o.z = __builtin_bit_cast(float, a2); o.w = __builtin_bit_cast(float, a3);
-    return o;
+    float o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int te = t + e;
+      const int pos = rev ? L - 1 - te : te;
+      const unsigned a = __builtin_amdgcn_raw_buffer_load_b32(r, (rowok && te < L) ? row + pos * 4 : kOOB, 0, 0);
+      o[e] = __builtin_bit_cast(float, a);
+    }
+    return make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+template <bool VEC>
+__device__ __forceinline__ void store_quad(rsrc_t r, int row, int t, int L, bool rev, bool rowok, float4 v) {
+  if constexpr (VEC) {
+    const bool ok = rowok && t < L;
+    const int pos = rev ? L - 4 - t : t;
+    const v4f f = rev ? (v4f){v.w, v.z, v.y, v.x} : (v4f){v.x, v.y, v.z, v.w};
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, f), r, ok ? row + pos * 4 : kOOB, 0, 0);
+  } else {
+    const float o[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int te = t + e;
+      const int pos = rev ? L - 1 - te : te;
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o[e]), r,
+                                            (rowok && te < L) ? row + pos * 4 : kOOB, 0, 0);
+    }
   }
 }
 
@@ -103,6 +128,8 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(const FwdParams p) {
   const int cwv = gw % p.wpg;                        // channel tile inside the group
   const int bk = gw / p.wpg;
   const int grp = bk % p.G, b = bk / p.G;
+  const int ugrp = p.ug < p.G ? (int)((p.u_map >> (4 * grp)) & 15) : grp;      // which channel block of u this direction reads
+  const bool rev = grp < 32 && ((p.rev_mask >> grp) & 1);          // this direction runs over the sequence backwards
 
   float* wl = smem + wave * WLDS;
   float* s_dl = wl;                                   // [CH][kTileStride]   delta'
@@ -125,8 +152,9 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(const FwdParams p) {
   const int r = lane >> 4, q = lane & 15;
   const int hc0 = cwv * CH + r;
   const int d0 = grp * p.H + cwv * CH;               // first channel of this wave (wave-uniform)
+  const int d0u = ugrp * p.H + cwv * CH;             // ... inside u
   // descriptors: wave-uniform bases, hardware range check does the tail masking
-  const rsrc_t ru = make_rsrc(p.u + b * p.u_sb + d0 * p.u_sd, ((int64_t)(p.dim - d0 - 1) * p.u_sd + p.L) * 4);
+  const rsrc_t ru = make_rsrc(p.u + b * p.u_sb + d0u * p.u_sd, ((int64_t)(p.ug * p.H - d0u - 1) * p.u_sd + p.L) * 4);
   const rsrc_t rd = make_rsrc(p.delta + b * p.d_sb + d0 * p.d_sd, ((int64_t)(p.dim - d0 - 1) * p.d_sd + p.L) * 4);
   const rsrc_t ro = make_rsrc(p.out + ((int64_t)b * p.dim + d0) * p.L, (int64_t)(p.dim - d0) * p.L * 4);
   const rsrc_t rB = make_rsrc(p.B + b * p.B_sb + grp * p.B_sg, ((int64_t)(kNState - 1) * p.B_sn + p.L) * 4);
@@ -140,53 +168,35 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(const FwdParams p) {
     const int dd = grp * p.H + (rvalid[i] ? hc0 + 4 * i : 0);
     Dv[i] = p.D ? p.D[dd] : 0.f;
     bv[i] = p.bias ? p.bias[dd] : 0.f;
-    uoff[i] = (int)((r + 4 * i) * p.u_sd + 4 * q) * 4;
-    doff[i] = (int)((r + 4 * i) * p.d_sd + 4 * q) * 4;
-    ooff[i] = ((r + 4 * i) * p.L + 4 * q) * 4;
+    uoff[i] = (int)((r + 4 * i) * p.u_sd) * 4;
+    doff[i] = (int)((r + 4 * i) * p.d_sd) * 4;
+    ooff[i] = ((r + 4 * i) * p.L) * 4;
   }
   // B/C staging: 8 float4 per lane per tile: k -> (which = k>>2, n = (k&3)*4 + r, column q)
   int bcoff[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     const int n = (k & 3) * 4 + r;
-    bcoff[k] = (int)(n * ((k >> 2) ? p.C_sn : p.B_sn) + 4 * q) * 4;
+    bcoff[k] = (int)(n * ((k >> 2) ? p.C_sn : p.B_sn)) * 4;
   }
 
   float4 pu[NLD], pd[NLD], pbc[8];
   auto issue_loads = [&](int t0) {
-    const bool tin = VEC ? (t0 + 4 * q < p.L) : true;
+    const int t = t0 + 4 * q;
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
-      if constexpr (VEC) {
-        pu[i] = bload4<true>(ru, uoff[i] + t0 * 4, rvalid[i] && tin);
-        pd[i] = bload4<true>(rd, doff[i] + t0 * 4, rvalid[i] && tin);
-      } else {
-        pu[i] = bload4<false>(ru, uoff[i] + t0 * 4, rvalid[i]);
-        pd[i] = bload4<false>(rd, doff[i] + t0 * 4, rvalid[i]);
-      }
+      pu[i] = load_quad<VEC>(ru, uoff[i], t, p.L, rev, rvalid[i]);
+      pd[i] = load_quad<VEC>(rd, doff[i], t, p.L, rev, rvalid[i]);
     }
 #pragma unroll
-    for (int k = 0; k < 8; ++k) pbc[k] = bload4<VEC>((k >> 2) ? rC : rB, bcoff[k] + t0 * 4, tin);
+    for (int k = 0; k < 8; ++k) pbc[k] = load_quad<VEC>((k >> 2) ? rC : rB, bcoff[k], t, p.L, rev, true);
   };
-  // NOTE (non-VEC): element-wise tail masking happens below (t + e < L) because a row tail lands in the next row.
 
   float4 yreg[NLD];
   auto store_tile = [&](int t0) {
     const bool st_en = !(p.dbg & 1);   // folded into the range check: no branch, so vmcnt stays countable
 #pragma unroll
-    for (int i = 0; i < NLD; ++i) {
-      const int t = t0 + 4 * q;
-      if constexpr (VEC) {
-        const bool ok = rvalid[i] && t < p.L && st_en;
-        const v4f yv = {yreg[i].x, yreg[i].y, yreg[i].z, yreg[i].w};
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, yv), ro, ok ? ooff[i] + t0 * 4 : kOOB, 0, 0);
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, f4get(yreg[i], e)), ro,
-                                                (rvalid[i] && t + e < p.L && st_en) ? ooff[i] + (t0 + e) * 4 : kOOB, 0, 0);
-      }
-    }
+    for (int i = 0; i < NLD; ++i) store_quad<VEC>(ro, ooff[i], t0 + 4 * q, p.L, rev, rvalid[i] && st_en, yreg[i]);
   };
 
   issue_loads(0);
@@ -214,13 +224,7 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(const FwdParams p) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const int n = (k & 3) * 4 + r;
-      float4 v = pbc[k];
-      if constexpr (!VEC) {   // zero the elements that belong to the next row
-        const int t = t0 + 4 * q;
-        v.x = t + 0 < p.L ? v.x : 0.f; v.y = t + 1 < p.L ? v.y : 0.f;
-        v.z = t + 2 < p.L ? v.z : 0.f; v.w = t + 3 < p.L ? v.w : 0.f;
-      }
-      *reinterpret_cast<float4*>(s_bc + ((k >> 2) * kNState + n) * kTileStride + 4 * q) = v;
+      *reinterpret_cast<float4*>(s_bc + ((k >> 2) * kNState + n) * kTileStride + 4 * q) = pbc[k];
     }
     // the previous tile's stores go out here: older than the loads issued next, so the wait for those
     // loads (one recurrence later) retires them for free and every path sees the same vmcnt picture
@@ -333,6 +337,10 @@ int scan_fwd_launch(const mm_scan_args* a, hipStream_t stream) {
   p.ntiles = (a->L + kTile - 1) / kTile;
   p.nchk = (a->L + kChunk - 1) / kChunk;
   p.dbg = (a->variant >> 8) & 0xff;
+  const bool shared = a->u_groups > 0 && a->u_groups < a->G;
+  p.ug = shared ? a->u_groups : a->G;
+  p.u_map = shared ? a->u_map : 0x76543210u;
+  p.rev_mask = a->rev_mask;
   int ns = (a->variant & 0xff) ? (a->variant & 0xff) : plan_fwd_variant(a->batch, a->G, p.H, a->L);
   if (ns != 1 && ns != 2 && ns != 4) return MM_ERR_UNSUPPORTED;
   int wpb = (a->variant >> 16) & 0xff;      // waves per workgroup (tuning knob; waves never synchronise)

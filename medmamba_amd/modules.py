@@ -24,7 +24,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 import torch.utils.checkpoint as checkpoint
 
-from .selective_scan_interface import selective_scan_fn
+from .selective_scan_interface import CROSS_SCAN_K_OF_G, cross_scan_fn, selective_scan_fn
 
 trunc_normal_ = nn.init.trunc_normal_   # timm.layers.trunc_normal_ == torch.nn.init.trunc_normal_
 
@@ -189,13 +189,32 @@ class SS2D(nn.Module):
         invwh_y = inv_y[:, 1].view(B, -1, W, H).transpose(2, 3).contiguous().view(B, -1, L)
         return out_y[:, 0], inv_y[:, 0], wh_y, invwh_y
 
+    def forward_core_fused(self, x):
+        """Same result as summing the four outputs of forward_corev0, without materialising the cross-scan:
+        x (B, D, H, W) -> y (B, H, W, D).  The scan kernel reads the row-major and the column-major image
+        (one transpose copy) and walks the two backward directions in reverse, so no flipped / 4x-stacked tensor
+        and no un-flip exists (MedMamba.py:256-257, 282-286, 298); projections are plain batched GEMMs."""
+        B, D, H, W = x.shape
+        L, R, N = H * W, self.dt_rank, self.d_state
+        perm = list(CROSS_SCAN_K_OF_G)                      # kernel direction g -> reference direction k
+        u2 = x.new_empty(B, 2, D, L)
+        u2[:, 0] = x.view(B, D, L)
+        u2[:, 1].view(B, D, W, H).copy_(x.transpose(2, 3))
+        Wx = self.x_proj_weight[perm].reshape(1, 2, 2 * (R + 2 * N), D)
+        x_dbl = torch.matmul(Wx, u2).view(B, 4, R + 2 * N, L)                              # :259
+        dts = torch.matmul(self.dt_projs_weight[perm].unsqueeze(0), x_dbl[:, :, :R])       # :262  (B,4,D,L)
+        y2 = cross_scan_fn(
+            u2.view(B, 2 * D, L), dts.view(B, 4 * D, L),
+            -torch.exp(self.A_logs.float().view(4, D, N)[perm]).view(4 * D, N),
+            x_dbl[:, :, R:R + N], x_dbl[:, :, R + N:],
+            self.Ds.float().view(4, D)[perm].reshape(-1), self.dt_projs_bias.float()[perm].reshape(-1)).view(B, 2, D, L)
+        y = y2[:, 0].view(B, D, H, W).permute(0, 2, 3, 1) + y2[:, 1].view(B, D, W, H).permute(0, 3, 2, 1)
+        return y.contiguous()
+
     def forward(self, x, **kwargs):
-        B, H, W, _ = x.shape
         x, z = self.in_proj(x).chunk(2, dim=-1)
         x = self.act(self.conv2d(x.permute(0, 3, 1, 2).contiguous()))
-        y1, y2, y3, y4 = self.forward_core(x)
-        assert y1.dtype == torch.float32
-        y = (y1 + y2 + y3 + y4).transpose(1, 2).contiguous().view(B, H, W, -1)
+        y = self.forward_core_fused(x)
         out = self.out_proj(self.out_norm(y) * F.silu(z))
         return out if self.dropout is None else self.dropout(out)
 

@@ -98,7 +98,7 @@ def _f32_rows(t):
 
 
 def _fill_common(a, u, delta, A, B, C, D, delta_bias, delta_softplus):
-    batch, dim, L = u.shape
+    batch, dim, L = delta.shape
     a.batch, a.dim, a.L, a.N, a.G = batch, dim, L, A.shape[1], B.shape[1]
     a.delta_softplus = int(bool(delta_softplus))
     a.u, a.delta, a.A, a.B, a.C = u.data_ptr(), delta.data_ptr(), A.data_ptr(), B.data_ptr(), C.data_ptr()
@@ -109,8 +109,62 @@ def _fill_common(a, u, delta, A, B, C, D, delta_bias, delta_softplus):
     a.C_sb, a.C_sg, a.C_sn = C.stride(0), C.stride(1), C.stride(2)
 
 
+def _launch_fwd(u, delta, A, B, C, D, delta_bias, delta_softplus, want_chk, variant=0, shared=(0, 0, 0)):
+    """mm_scan_fwd on torch's current stream. Returns (out (batch, G*H, L), x_chk or None)."""
+    batch, dim, L = delta.shape
+    out = torch.empty((batch, dim, L), device=u.device, dtype=torch.float32)
+    x_chk = None
+    if want_chk:
+        chunk = _lib.scan_chunk()
+        x_chk = torch.empty((batch, dim, (L + chunk - 1) // chunk, A.shape[1]), device=u.device, dtype=torch.float32)
+    a = _lib.ScanArgs()
+    _fill_common(a, u, delta, A, B, C, D, delta_bias, delta_softplus)
+    a.out, a.x_chk, a.variant = out.data_ptr(), _ptr(x_chk), int(variant)
+    a.u_groups, a.u_map, a.rev_mask = shared
+    with torch.cuda.device(u.device):
+        t0 = KERNEL_TIMER.start()
+        rc = _lib.lib().mm_scan_fwd(a, torch.cuda.current_stream().cuda_stream)
+        KERNEL_TIMER.stop("scan_fwd", t0, scan_bytes_fwd(batch, dim, L, A.shape[1], B.shape[1]))
+    _lib.check(rc, "mm_scan_fwd")
+    return out, x_chk
+
+
+def _launch_bwd(u, delta, A, B, C, D, delta_bias, x_chk, dout, delta_softplus, shared=(0, 0, 0)):
+    """mm_scan_bwd on torch's current stream. Returns du (per group), ddelta, dA, dB, dC, dD, dbias."""
+    batch, dim, L = delta.shape
+    G, N = B.shape[1], A.shape[1]
+    dev = u.device
+    du, ddelta = torch.empty_like(delta), torch.empty_like(delta)
+    # accumulated with atomics across batch / channel tiles -> zero-filled here (header contract)
+    dA = torch.zeros((dim, N), device=dev, dtype=torch.float32)
+    dB = torch.zeros((batch, G, N, L), device=dev, dtype=torch.float32)
+    dC = torch.zeros((batch, G, N, L), device=dev, dtype=torch.float32)
+    dD = None if D is None else torch.zeros((dim,), device=dev, dtype=torch.float32)
+    dbias = None if delta_bias is None else torch.zeros((dim,), device=dev, dtype=torch.float32)
+    a = _lib.ScanArgs()
+    _fill_common(a, u, delta, A, B, C, D, delta_bias, delta_softplus)
+    a.x_chk, a.dout = x_chk.data_ptr(), dout.data_ptr()
+    a.du, a.ddelta, a.dA, a.dB, a.dC = du.data_ptr(), ddelta.data_ptr(), dA.data_ptr(), dB.data_ptr(), dC.data_ptr()
+    a.dD, a.ddelta_bias = _ptr(dD), _ptr(dbias)
+    a.u_groups, a.u_map, a.rev_mask = shared
+    with torch.cuda.device(dev):
+        t0 = KERNEL_TIMER.start()
+        rc = _lib.lib().mm_scan_bwd(a, torch.cuda.current_stream().cuda_stream)
+        KERNEL_TIMER.stop("scan_bwd", t0, scan_bytes_bwd(batch, dim, L, N, G))
+    _lib.check(rc, "mm_scan_bwd")
+    return du, ddelta, dA, dB, dC, dD, dbias
+
+
+def _prep(u, delta, A, B, C, D, delta_bias):
+    u, delta, B, C = _f32_rows(u), _f32_rows(delta), _f32_rows(B), _f32_rows(C)
+    A = A.float().contiguous()
+    D = None if D is None else D.float().contiguous()
+    delta_bias = None if delta_bias is None else delta_bias.float().contiguous()
+    return u, delta, A, B, C, D, delta_bias
+
+
 class SelectiveScanFn(torch.autograd.Function):
-    """Autograd wrapper around mm_scan_fwd / mm_scan_bwd.
+    """Autograd wrapper around mm_scan_fwd / mm_scan_bwd (the selective_scan_fn operator).
 
     Saved for backward: u, delta, A, B, C, D, delta_bias and the state checkpoints x_chk
     (batch, dim, ceil(L/16), 16) that the forward kernel writes — the backward kernel recomputes the
@@ -118,26 +172,9 @@ class SelectiveScanFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, u, delta, A, B, C, D=None, delta_bias=None, delta_softplus=False, variant=0):
-        u, delta, B, C = _f32_rows(u), _f32_rows(delta), _f32_rows(B), _f32_rows(C)
-        A = A.float().contiguous()
-        D = None if D is None else D.float().contiguous()
-        delta_bias = None if delta_bias is None else delta_bias.float().contiguous()
-        batch, dim, L = u.shape
+        u, delta, A, B, C, D, delta_bias = _prep(u, delta, A, B, C, D, delta_bias)
         need_grad = any(ctx.needs_input_grad[:7])
-        out = torch.empty((batch, dim, L), device=u.device, dtype=torch.float32)
-        x_chk = None
-        if need_grad:
-            chunk = _lib.scan_chunk()
-            x_chk = torch.empty((batch, dim, (L + chunk - 1) // chunk, A.shape[1]), device=u.device,
-                                dtype=torch.float32)
-        a = _lib.ScanArgs()
-        _fill_common(a, u, delta, A, B, C, D, delta_bias, delta_softplus)
-        a.out, a.x_chk, a.variant = out.data_ptr(), _ptr(x_chk), int(variant)
-        with torch.cuda.device(u.device):
-            t0 = KERNEL_TIMER.start()
-            rc = _lib.lib().mm_scan_fwd(a, torch.cuda.current_stream().cuda_stream)
-            KERNEL_TIMER.stop("scan_fwd", t0, scan_bytes_fwd(batch, dim, L, A.shape[1], B.shape[1]))
-        _lib.check(rc, "mm_scan_fwd")
+        out, x_chk = _launch_fwd(u, delta, A, B, C, D, delta_bias, delta_softplus, need_grad, variant)
         if need_grad:
             ctx.save_for_backward(u, delta, A, B, C, D, delta_bias, x_chk)
             ctx.delta_softplus = delta_softplus
@@ -146,29 +183,57 @@ class SelectiveScanFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         u, delta, A, B, C, D, delta_bias, x_chk = ctx.saved_tensors
-        dout = dout.float().contiguous()
-        batch, dim, L = u.shape
-        G, N = B.shape[1], A.shape[1]
-        dev = u.device
-        du, ddelta = torch.empty_like(dout), torch.empty_like(dout)
-        # accumulated with atomics across batch / channel tiles -> zero-filled here (header contract)
-        dA = torch.zeros((dim, N), device=dev, dtype=torch.float32)
-        dB = torch.zeros((batch, G, N, L), device=dev, dtype=torch.float32)
-        dC = torch.zeros((batch, G, N, L), device=dev, dtype=torch.float32)
-        dD = None if D is None else torch.zeros((dim,), device=dev, dtype=torch.float32)
-        dbias = None if delta_bias is None else torch.zeros((dim,), device=dev, dtype=torch.float32)
-        a = _lib.ScanArgs()
-        _fill_common(a, u, delta, A, B, C, D, delta_bias, ctx.delta_softplus)
-        a.x_chk, a.dout = x_chk.data_ptr(), dout.data_ptr()
-        a.du, a.ddelta, a.dA, a.dB, a.dC = (du.data_ptr(), ddelta.data_ptr(), dA.data_ptr(), dB.data_ptr(),
-                                            dC.data_ptr())
-        a.dD, a.ddelta_bias = _ptr(dD), _ptr(dbias)
-        with torch.cuda.device(dev):
-            t0 = KERNEL_TIMER.start()
-            rc = _lib.lib().mm_scan_bwd(a, torch.cuda.current_stream().cuda_stream)
-            KERNEL_TIMER.stop("scan_bwd", t0, scan_bytes_bwd(batch, dim, L, N, G))
-        _lib.check(rc, "mm_scan_bwd")
-        return du, ddelta, dA, dB, dC, dD, dbias, None, None
+        r = _launch_bwd(u, delta, A, B, C, D, delta_bias, x_chk, dout.float().contiguous(), ctx.delta_softplus)
+        return (*r, None, None)
+
+
+# SS2D direction order used by cross_scan_fn (kernel group g): g = 0 row-major forward, 1 row-major backward,
+# 2 column-major forward, 3 column-major backward  (= reference directions k = 0, 2, 1, 3; MedMamba.py:256-257).
+CROSS_SCAN_K_OF_G = (0, 2, 1, 3)
+_CROSS_SHARED = (2, 0x1100, 0b1010)      # u_groups, u_map (block of g: 0,0,1,1), rev_mask (g = 1, 3 reversed)
+
+
+class CrossScanFn(torch.autograd.Function):
+    """4-direction selective scan of SS2D without materialising the cross-scan (MedMamba.py:256-257, 273-286).
+
+    u2:    (batch, 2*D, L)  channel block 0 = image in row-major order, block 1 = column-major order
+    delta: (batch, 4*D, L), B, C: (batch, 4, N, L) — per direction g (order CROSS_SCAN_K_OF_G), all stored in
+           POSITION order of their image order; the backward directions (g = 1, 3) are walked in reverse by the kernel
+    returns y2 (batch, 2*D, L): block 0 = sum of the two row-major directions, block 1 = sum of the two
+           column-major directions, both in position order (the un-flip of MedMamba.py:282 never happens).
+    The sum over a direction pair is linear, so the backward feeds the same gradient block to both directions
+    (the kernel reads dout with the u block mapping) and sums the two du blocks."""
+
+    @staticmethod
+    def forward(ctx, u2, delta, A, B, C, D, delta_bias):
+        u2, delta, A, B, C, D, delta_bias = _prep(u2, delta, A, B, C, D, delta_bias)
+        need_grad = any(ctx.needs_input_grad)
+        out, x_chk = _launch_fwd(u2, delta, A, B, C, D, delta_bias, True, need_grad, 0, _CROSS_SHARED)
+        bsz, dim, L = out.shape
+        o = out.view(bsz, 2, 2, dim // 4, L)
+        y2 = (o[:, :, 0] + o[:, :, 1]).view(bsz, dim // 2, L)
+        if need_grad:
+            ctx.save_for_backward(u2, delta, A, B, C, D, delta_bias, x_chk)
+        return y2
+
+    @staticmethod
+    def backward(ctx, dy2):
+        u2, delta, A, B, C, D, delta_bias, x_chk = ctx.saved_tensors
+        du, ddelta, dA, dB, dC, dD, dbias = _launch_bwd(u2, delta, A, B, C, D, delta_bias, x_chk,
+                                                        dy2.float().contiguous(), True, _CROSS_SHARED)
+        bsz, dim, L = du.shape
+        d = du.view(bsz, 2, 2, dim // 4, L)
+        du2 = (d[:, :, 0] + d[:, :, 1]).view(bsz, dim // 2, L)
+        return du2, ddelta, dA, dB, dC, dD, dbias
+
+
+def cross_scan_fn(u2, delta, A, B, C, D, delta_bias):
+    """See CrossScanFn. HIP tensors only."""
+    if not u2.is_cuda:
+        raise RuntimeError("cross_scan_fn: tensors must live on a HIP device (medmamba_amd has no CPU path)")
+    if A.shape[1] != 16 or B.shape[1] != 4 or delta.shape[1] != 2 * u2.shape[1]:
+        raise NotImplementedError("cross_scan_fn: expects 4 directions, d_state 16, delta with 4*D channels")
+    return CrossScanFn.apply(u2, delta, A, B, C, D, delta_bias)
 
 
 def selective_scan_fn(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=False,

@@ -211,3 +211,19 @@ def c_selective_scan_fn(u, delta, A, B, C, D=None, z=None, delta_bias=None,
                         delta_softplus=False, return_last_state=False):
     assert z is None and not return_last_state
     return CScanFn.apply(u, delta, A, B, C, D, delta_bias, delta_softplus)
+
+
+def c_cross_scan_fn(u2, delta, A, B, C, D, delta_bias):
+    """Test double for medmamba_amd.cross_scan_fn built on the oracle: materialises what the kernel avoids.
+    Direction g reads image-order block g // 2 and is time-reversed for odd g (the flips of MedMamba.py:257),
+    runs the oracle scan on explicitly time-ordered tensors, un-flips (MedMamba.py:282) and sums each pair."""
+    bsz, d2, L = u2.shape
+    Dn = d2 // 2
+    tm = lambda t, g: t.flip(-1) if g % 2 else t
+    u2v, dv = u2.view(bsz, 2, Dn, L), delta.view(bsz, 4, Dn, L)
+    u4 = torch.stack([tm(u2v[:, g // 2], g) for g in range(4)], 1).reshape(bsz, 4 * Dn, L)
+    d4 = torch.stack([tm(dv[:, g], g) for g in range(4)], 1).reshape(bsz, 4 * Dn, L)
+    B4 = torch.stack([tm(B[:, g], g) for g in range(4)], 1)
+    C4 = torch.stack([tm(C[:, g], g) for g in range(4)], 1)
+    o4 = CScanFn.apply(u4, d4, A, B4, C4, D, delta_bias, True).view(bsz, 4, Dn, L)
+    return torch.stack([o4[:, 0] + o4[:, 1].flip(-1), o4[:, 2] + o4[:, 3].flip(-1)], 1).view(bsz, 2 * Dn, L)

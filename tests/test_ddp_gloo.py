@@ -19,8 +19,9 @@ def _free_port():
 
 def _build_model():
     from medmamba_amd import modules as M
-    from oracle.scan_ref import c_selective_scan_fn
-    M.selective_scan_fn = c_selective_scan_fn          # test double; the product has no CPU scan
+    from oracle.scan_ref import c_cross_scan_fn, c_selective_scan_fn
+    M.selective_scan_fn = c_selective_scan_fn          # test doubles; the product has no CPU scan
+    M.cross_scan_fn = c_cross_scan_fn
     torch.manual_seed(7)
     net = M.VSSM(num_classes=3, depths=[1, 1], dims=[16, 32], drop_path_rate=0.0)
     net.eval()       # BatchNorm uses running stats -> per-sample independence -> DDP mean == big-batch gradient

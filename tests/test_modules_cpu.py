@@ -10,12 +10,13 @@ import torch
 
 from conftest import GOLDEN, load_golden, split_sd
 from medmamba_amd import modules as M
-from oracle.scan_ref import c_selective_scan_fn
+from oracle.scan_ref import c_cross_scan_fn, c_selective_scan_fn
 
 
 @pytest.fixture()
 def oracle_scan(monkeypatch):
     monkeypatch.setattr(M, "selective_scan_fn", c_selective_scan_fn)
+    monkeypatch.setattr(M, "cross_scan_fn", c_cross_scan_fn)
 
 
 def test_state_dict_layout_matches_reference_tiny():
@@ -87,6 +88,12 @@ def test_ss2d_glue_with_injected_oracle_scan(name, oracle_scan):
     for k, p in m.named_parameters():
         w = fx["grad/" + k]
         assert np.abs(p.grad.numpy() - w).max() <= 2e-4 * max(1.0, np.abs(w).max()), k
+    # the reference-compatible 4-output core (forward_corev0) is still there and agrees with the fused core
+    xc = torch.from_numpy(fx["conv_out"])
+    y4 = m.forward_corev0(xc)
+    assert np.abs(sum(y4).detach().numpy() - fx["core_out"]).max() <= 2e-5 * max(1.0, np.abs(fx["core_out"]).max())
+    yf = m.forward_core_fused(xc).permute(0, 3, 1, 2).reshape(fx["core_out"].shape)
+    assert np.abs(yf.detach().numpy() - fx["core_out"]).max() <= 2e-5 * max(1.0, np.abs(fx["core_out"]).max())
 
 
 def test_block_and_tiny_model_with_injected_oracle_scan(oracle_scan):

@@ -181,3 +181,66 @@ def test_full_size_properties_stage1():
                              Cs[b:b + 1, grp:grp + 1].cpu(), D[sl].cpu(), bias[sl].cpu(), True, f64=True)
             got = out[b:b + 1, sl].cpu().numpy()
             assert np.abs(got - o64).max() <= 5e-5 * max(1.0, np.abs(o64).max())
+
+
+def test_cross_scan_matches_explicit_flips_and_oracle():
+    """cross_scan_fn (shared u blocks + reversed directions, nothing flipped in memory) == the reference's
+    materialised cross-scan (stack / flip) pushed through the oracle, forward and backward."""
+    from oracle.scan_ref import c_scan_bwd, c_scan_fwd
+    from medmamba_amd import cross_scan_fn
+    dev = _dev()
+    g = torch.Generator().manual_seed(3)
+    Bz, D, L, N = 2, 24, 100, 16
+    u2 = torch.randn(Bz, 2, D, L, generator=g)
+    delta = torch.randn(Bz, 4, D, L, generator=g)
+    A = -torch.exp(torch.randn(4 * D, N, generator=g) * 0.5)
+    Bm, Cm = torch.randn(Bz, 4, N, L, generator=g), torch.randn(Bz, 4, N, L, generator=g)
+    Dp, bias = torch.randn(4 * D, generator=g), torch.randn(4 * D, generator=g) - 3
+    dy2 = torch.randn(Bz, 2, D, L, generator=g)
+    # oracle on explicitly time-ordered tensors: direction g = (block g//2, reversed if g odd)
+    tm = lambda t, gi: t.flip(-1) if gi % 2 else t
+    u4 = torch.stack([tm(u2[:, gi // 2], gi) for gi in range(4)], 1).reshape(Bz, 4 * D, L)
+    d4 = torch.stack([tm(delta[:, gi], gi) for gi in range(4)], 1).reshape(Bz, 4 * D, L)
+    B4 = torch.stack([tm(Bm[:, gi], gi) for gi in range(4)], 1)
+    C4 = torch.stack([tm(Cm[:, gi], gi) for gi in range(4)], 1)
+    o4 = torch.from_numpy(c_scan_fwd(u4, d4, A, B4, C4, Dp, bias, True, f64=True)).view(Bz, 4, D, L)
+    want = torch.stack([o4[:, 0] + o4[:, 1].flip(-1), o4[:, 2] + o4[:, 3].flip(-1)], 1)
+    ins = [t.to(dev).requires_grad_() for t in (u2.view(Bz, 2 * D, L), delta.view(Bz, 4 * D, L), A, Bm, Cm, Dp, bias)]
+    y2 = cross_scan_fn(*ins)
+    err = (y2.detach().cpu().double().view(Bz, 2, D, L) - want).abs().max().item()
+    assert err <= 5e-5 * want.abs().max().item(), err
+    y2.backward(dy2.view(Bz, 2 * D, L).to(dev))
+    dout4 = torch.stack([tm(dy2[:, gi // 2], gi) for gi in range(4)], 1).reshape(Bz, 4 * D, L)
+    r = c_scan_bwd(u4, d4, A, B4, C4, Dp, bias, dout4, True)
+    du4 = torch.from_numpy(r["du"]).view(Bz, 4, D, L)
+    want_du = torch.stack([du4[:, 0] + du4[:, 1].flip(-1), du4[:, 2] + du4[:, 3].flip(-1)], 1).view(Bz, 2 * D, L)
+    unflip = lambda t: torch.stack([tm(t[:, gi], gi) for gi in range(4)], 1)
+    wants = [want_du, unflip(torch.from_numpy(r["ddelta"]).view(Bz, 4, D, L)).reshape(Bz, 4 * D, L),
+             torch.from_numpy(r["dA"]), unflip(torch.from_numpy(r["dB"])), unflip(torch.from_numpy(r["dC"])),
+             torch.from_numpy(r["dD"]), torch.from_numpy(r["ddelta_bias"])]
+    for name, t, w in zip(["du2", "ddelta", "dA", "dB", "dC", "dD", "dbias"], ins, wants):
+        e = (t.grad.cpu().double() - w).abs().max().item() / max(1.0, w.abs().max().item())
+        assert e <= BWD_RTOL, (name, e)
+
+
+@pytest.mark.parametrize("L", [49, 130])
+def test_cross_scan_unaligned_lengths(L):
+    """L % 4 != 0 exercises the dword path of the reversed directions."""
+    from oracle.scan_ref import c_scan_fwd
+    from medmamba_amd import cross_scan_fn
+    dev = _dev()
+    g = torch.Generator().manual_seed(L)
+    Bz, D, N = 1, 8, 16
+    u2 = torch.randn(Bz, 2, D, L, generator=g); delta = torch.randn(Bz, 4, D, L, generator=g)
+    A = -torch.exp(torch.randn(4 * D, N, generator=g) * 0.5)
+    Bm, Cm = torch.randn(Bz, 4, N, L, generator=g), torch.randn(Bz, 4, N, L, generator=g)
+    Dp, bias = torch.randn(4 * D, generator=g), torch.randn(4 * D, generator=g) - 3
+    tm = lambda t, gi: t.flip(-1) if gi % 2 else t
+    u4 = torch.stack([tm(u2[:, gi // 2], gi) for gi in range(4)], 1).reshape(Bz, 4 * D, L)
+    d4 = torch.stack([tm(delta[:, gi], gi) for gi in range(4)], 1).reshape(Bz, 4 * D, L)
+    B4 = torch.stack([tm(Bm[:, gi], gi) for gi in range(4)], 1); C4 = torch.stack([tm(Cm[:, gi], gi) for gi in range(4)], 1)
+    o4 = torch.from_numpy(c_scan_fwd(u4, d4, A, B4, C4, Dp, bias, True, f64=True)).view(Bz, 4, D, L)
+    want = torch.stack([o4[:, 0] + o4[:, 1].flip(-1), o4[:, 2] + o4[:, 3].flip(-1)], 1)
+    with torch.no_grad():
+        y2 = cross_scan_fn(*[t.to(dev) for t in (u2.view(Bz, 2 * D, L), delta.view(Bz, 4 * D, L), A, Bm, Cm, Dp, bias)])
+    assert (y2.cpu().double().view(Bz, 2, D, L) - want).abs().max().item() <= 5e-5 * want.abs().max().item()
