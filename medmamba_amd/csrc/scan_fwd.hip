@@ -27,6 +27,8 @@
 namespace {
 using namespace mm;
 
+constexpr int fwd_tile(int ns, bool lean) { return (lean && ns >= 2) ? 32 : 64; }
+
 struct FwdParams {
   const float* __restrict__ u;
   const float* __restrict__ delta;
@@ -107,11 +109,22 @@ __device__ __forceinline__ float f4get(const float4& v, int i) {
 }
 
 // NS: states per lane (1,2,4).  VEC: L % 4 == 0 and all rows 16-B aligned.  SP: delta_softplus.
-template <int NS, bool VEC, bool SP>
+// LEAN: register diet for shapes with plenty of wavefronts (>= 3 per SIMD hide latency by themselves): B/C are
+//       loaded where they are consumed instead of one tile ahead, the recurrence uses one operand set, and the
+//       tile's stores are issued as soon as they exist.  Without LEAN (few, long wavefronts) everything is
+//       software-pipelined in registers.
+template <int NS, bool VEC, bool SP, bool LEAN>
 __global__ __launch_bounds__(256) void scan_fwd_kernel(const FwdParams p) {
   constexpr int SG = kNState / NS;   // lanes per channel
   constexpr int CH = kWave / SG;     // channels per wave (= 4*NS)
-  constexpr int NLD = CH / 4;        // float4 row-loads per lane per tensor per tile (= NS)
+  // tile geometry: LEAN wavefronts use 32-step tiles (half the LDS per wave -> >= 3 waves per SIMD fit)
+  constexpr int kTile = fwd_tile(NS, LEAN);
+  constexpr int kTileStride = kTile + 4;          // +16 B pad: conflict-free b128 rows for 32 and 64
+  constexpr int QL = kTile / 4;                   // lanes (float4 columns) per row
+  constexpr int RPI = kWave / QL;                 // rows per load instruction
+  constexpr int NLD = CH / RPI;                   // float4 row-loads per lane per tensor per tile
+  constexpr int NBC = 2 * kNState / RPI;          // float4 B/C staging loads per lane per tile
+  constexpr int NPBC = LEAN ? 1 : NBC;
   constexpr int WLDS = 2 * CH * kTileStride + 2 * kNState * kTileStride;   // floats of LDS per wave
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -149,7 +162,7 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(const FwdParams p) {
   }
 
   // ---- staging identity: lane -> (row r of a 4-row group, float4 column q); rows 4*i + r
-  const int r = lane >> 4, q = lane & 15;
+  const int r = lane / QL, q = lane % QL;
   const int hc0 = cwv * CH + r;
   const int d0 = grp * p.H + cwv * CH;               // first channel of this wave (wave-uniform)
   const int d0u = ugrp * p.H + cwv * CH;             // ... inside u
@@ -164,23 +177,23 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(const FwdParams p) {
   int uoff[NLD], doff[NLD], ooff[NLD];
 #pragma unroll
   for (int i = 0; i < NLD; ++i) {
-    rvalid[i] = hc0 + 4 * i < p.H;
-    const int dd = grp * p.H + (rvalid[i] ? hc0 + 4 * i : 0);
+    rvalid[i] = hc0 + RPI * i < p.H;
+    const int dd = grp * p.H + (rvalid[i] ? hc0 + RPI * i : 0);
     Dv[i] = p.D ? p.D[dd] : 0.f;
     bv[i] = p.bias ? p.bias[dd] : 0.f;
-    uoff[i] = (int)((r + 4 * i) * p.u_sd) * 4;
-    doff[i] = (int)((r + 4 * i) * p.d_sd) * 4;
-    ooff[i] = ((r + 4 * i) * p.L) * 4;
+    uoff[i] = (int)((r + RPI * i) * p.u_sd) * 4;
+    doff[i] = (int)((r + RPI * i) * p.d_sd) * 4;
+    ooff[i] = ((r + RPI * i) * p.L) * 4;
   }
-  // B/C staging: 8 float4 per lane per tile: k -> (which = k>>2, n = (k&3)*4 + r, column q)
-  int bcoff[8];
+  // B/C staging: NBC float4 per lane per tile: k -> (which = k / (NBC/2), n = (k % (NBC/2)) * RPI + r, column q)
+  int bcoff[NBC];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const int n = (k & 3) * 4 + r;
-    bcoff[k] = (int)(n * ((k >> 2) ? p.C_sn : p.B_sn)) * 4;
+  for (int k = 0; k < NBC; ++k) {
+    const int n = (k % (NBC / 2)) * RPI + r;
+    bcoff[k] = (int)(n * ((k >= NBC / 2) ? p.C_sn : p.B_sn)) * 4;
   }
 
-  float4 pu[NLD], pd[NLD], pbc[8];
+  float4 pu[NLD], pd[NLD], pbc[NPBC];
   auto issue_loads = [&](int t0) {
     const int t = t0 + 4 * q;
 #pragma unroll
@@ -188,8 +201,10 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(const FwdParams p) {
       pu[i] = load_quad<VEC>(ru, uoff[i], t, p.L, rev, rvalid[i]);
       pd[i] = load_quad<VEC>(rd, doff[i], t, p.L, rev, rvalid[i]);
     }
+    if constexpr (!LEAN) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) pbc[k] = load_quad<VEC>((k >> 2) ? rC : rB, bcoff[k], t, p.L, rev, true);
+      for (int k = 0; k < NBC; ++k) pbc[k] = load_quad<VEC>((k >= NBC / 2) ? rC : rB, bcoff[k], t, p.L, rev, true);
+    }
   };
 
   float4 yreg[NLD];
@@ -217,18 +232,22 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(const FwdParams p) {
         (&du.x)[e] = v * f4get(pu[i], e);
       }
       uD[i] = make_float4(pu[i].x * Dv[i], pu[i].y * Dv[i], pu[i].z * Dv[i], pu[i].w * Dv[i]);
-      const int off = (4 * i + r) * kTileStride + 4 * q;
+      const int off = (RPI * i + r) * kTileStride + 4 * q;
       *reinterpret_cast<float4*>(s_dl + off) = dl;
       *reinterpret_cast<float4*>(s_du + off) = du;
     }
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int n = (k & 3) * 4 + r;
-      *reinterpret_cast<float4*>(s_bc + ((k >> 2) * kNState + n) * kTileStride + 4 * q) = pbc[k];
+    for (int k = 0; k < NBC; ++k) {
+      const int n = (k % (NBC / 2)) * RPI + r;
+      const bool isC = k >= NBC / 2;
+      const float4 v = LEAN ? load_quad<VEC>(isC ? rC : rB, bcoff[k], t0 + 4 * q, p.L, rev, true) : pbc[LEAN ? 0 : k];
+      *reinterpret_cast<float4*>(s_bc + ((isC ? kNState : 0) + n) * kTileStride + 4 * q) = v;
     }
     // the previous tile's stores go out here: older than the loads issued next, so the wait for those
     // loads (one recurrence later) retires them for free and every path sees the same vmcnt picture
-    if (tile > 0) store_tile(t0 - kTile);
+    if constexpr (!LEAN) {
+      if (tile > 0) store_tile(t0 - kTile);
+    }
     if (tile + 1 < p.ntiles) issue_loads(t0 + kTile);
 
     // ---- phase 2: the recurrence over this tile, 4 steps per group
@@ -264,13 +283,19 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(const FwdParams p) {
       }
       if (g == 0) *reinterpret_cast<float4*>(s_du + c * kTileStride + 4 * tg) = y4;
       if (p.x_chk != nullptr && ((tg & 3) == 3 || tg == ngroups - 1) && cvalid) {
-        const int chunk = (t0 >> 4) + (tg >> 2);
+        const int chunk = (t0 >> 4) + (tg >> 2);   // kChunk = 16 divides both tile sizes
         float* dst = p.x_chk + (((int64_t)b * p.dim + d) * p.nchk + chunk) * kNState + g * NS;
 #pragma unroll
         for (int j = 0; j < NS; ++j) dst[j] = x[j];
       }
     };
     // two operand register sets, rotated by hand (a `cur = nxt` copy costs 40 v_mov per group)
+    if constexpr (LEAN) {
+      for (int tg = 0; tg < ngroups; ++tg) {
+        const Ops o = load_ops(tg);
+        compute(o, tg);
+      }
+    } else {
     Ops opA = load_ops(0);
     for (int tg = 0; tg < ngroups; tg += 2) {
       Ops opB = load_ops(min(tg + 1, ngroups - 1));
@@ -282,31 +307,40 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(const FwdParams p) {
       if (tg + 1 < ngroups) compute(opB, tg + 1);
       __builtin_amdgcn_sched_barrier(0);
     }
+    }
 
     // ---- phase 3: y (+ D*u) LDS -> registers -> global (coalesced like the loads)
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
-      const float4 y = *reinterpret_cast<const float4*>(s_du + (4 * i + r) * kTileStride + 4 * q);
+      const float4 y = *reinterpret_cast<const float4*>(s_du + (RPI * i + r) * kTileStride + 4 * q);
       yreg[i] = make_float4(y.x + uD[i].x, y.y + uD[i].y, y.z + uD[i].z, y.w + uD[i].w);
     }
+    if constexpr (LEAN) store_tile(t0);
   }
-  store_tile((p.ntiles - 1) * kTile);
+  if constexpr (!LEAN) store_tile((p.ntiles - 1) * kTile);
 }
 
-template <int NS, bool VEC, bool SP>
+template <int NS, bool VEC, bool SP, bool LEAN>
 int launch(const FwdParams& p, int nblocks, int wpb, hipStream_t stream) {
   constexpr int CH = 4 * NS;
-  const size_t lds = sizeof(float) * (size_t)wpb * (2 * CH * kTileStride + 2 * kNState * kTileStride);
+  constexpr int TS = fwd_tile(NS, LEAN) + 4;
+  const size_t lds = sizeof(float) * (size_t)wpb * (2 * CH * TS + 2 * kNState * TS);
   if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute((const void*)scan_fwd_kernel<NS, VEC, SP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((scan_fwd_kernel<NS, VEC, SP>), dim3(nblocks), dim3(wpb * 64), lds, stream, p);
+    (void)hipFuncSetAttribute((const void*)scan_fwd_kernel<NS, VEC, SP, LEAN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  FwdParams q = p;
+  q.ntiles = (p.L + fwd_tile(NS, LEAN) - 1) / fwd_tile(NS, LEAN);
+  hipLaunchKernelGGL((scan_fwd_kernel<NS, VEC, SP, LEAN>), dim3(nblocks), dim3(wpb * 64), lds, stream, q);
   return (int)hipGetLastError();
 }
 
+template <int NS, bool LEAN>
+int launch_l(const FwdParams& p, int nblocks, int wpb, bool vec, bool sp, hipStream_t stream) {
+  if (vec) return sp ? launch<NS, true, true, LEAN>(p, nblocks, wpb, stream) : launch<NS, true, false, LEAN>(p, nblocks, wpb, stream);
+  return sp ? launch<NS, false, true, LEAN>(p, nblocks, wpb, stream) : launch<NS, false, false, LEAN>(p, nblocks, wpb, stream);
+}
 template <int NS>
-int launch_ns(const FwdParams& p, int nblocks, int wpb, bool vec, bool sp, hipStream_t stream) {
-  if (vec) return sp ? launch<NS, true, true>(p, nblocks, wpb, stream) : launch<NS, true, false>(p, nblocks, wpb, stream);
-  return sp ? launch<NS, false, true>(p, nblocks, wpb, stream) : launch<NS, false, false>(p, nblocks, wpb, stream);
+int launch_ns(const FwdParams& p, int nblocks, int wpb, bool vec, bool sp, bool lean, hipStream_t stream) {
+  return lean ? launch_l<NS, true>(p, nblocks, wpb, vec, sp, stream) : launch_l<NS, false>(p, nblocks, wpb, vec, sp, stream);
 }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -321,9 +355,8 @@ namespace mm {
 int plan_fwd_variant(int batch, int G, int H, int L) {
   (void)L;
   const long seqs = (long)batch * G * H;
-  if (seqs / 16 >= 3072) return 4;
-  if (seqs / 8 >= 2048) return 2;
-  if (seqs / 16 >= 1536) return 4;
+  if (seqs / 16 >= 3072) return 4;     // >= 3 waves per SIMD at 4 states per lane (LEAN variant)
+  if (seqs / 8 >= 1024) return 2;      // fewer sequences: halve the states per lane to double the wave count
   return 1;
 }
 
@@ -344,7 +377,7 @@ int scan_fwd_launch(const mm_scan_args* a, hipStream_t stream) {
   int ns = (a->variant & 0xff) ? (a->variant & 0xff) : plan_fwd_variant(a->batch, a->G, p.H, a->L);
   if (ns != 1 && ns != 2 && ns != 4) return MM_ERR_UNSUPPORTED;
   int wpb = (a->variant >> 16) & 0xff;      // waves per workgroup (tuning knob; waves never synchronise)
-  if (wpb <= 0) wpb = 2;
+  if (wpb <= 0) wpb = (ns == 4 && (long)a->batch * a->dim / 16 >= 3072) ? 4 : 2;
   if (wpb > 4) wpb = 4;
   const int CH = 4 * ns;
   p.wpg = (p.H + CH - 1) / CH;
@@ -360,10 +393,14 @@ int scan_fwd_launch(const mm_scan_args* a, hipStream_t stream) {
                    a->delta_sd % 4 == 0 && a->B_sb % 4 == 0 && a->B_sg % 4 == 0 && a->B_sn % 4 == 0 &&
                    a->C_sb % 4 == 0 && a->C_sg % 4 == 0 && a->C_sn % 4 == 0;
   const bool sp = a->delta_softplus != 0;
+  // variant bit 24: force LEAN on, bit 25: force LEAN off; default: lean when the grid offers >= 3 waves per SIMD
+  bool lean = p.nwaves_total >= 3 * 1024;
+  if (a->variant & (1 << 24)) lean = true;
+  if (a->variant & (1 << 25)) lean = false;
   switch (ns) {
-    case 1: return launch_ns<1>(p, nblocks, wpb, vec, sp, stream);
-    case 2: return launch_ns<2>(p, nblocks, wpb, vec, sp, stream);
-    default: return launch_ns<4>(p, nblocks, wpb, vec, sp, stream);
+    case 1: return launch_ns<1>(p, nblocks, wpb, vec, sp, lean, stream);
+    case 2: return launch_ns<2>(p, nblocks, wpb, vec, sp, lean, stream);
+    default: return launch_ns<4>(p, nblocks, wpb, vec, sp, lean, stream);
   }
 }
 
