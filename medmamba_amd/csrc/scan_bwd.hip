@@ -1,18 +1,20 @@
 // Selective-scan backward for gfx950 (MI355X).  Replaces mamba_ssm's selective_scan_cuda.bwd behind
 // SelectiveScanFn.backward (autograd of the call at MedMamba.py:273-279; the adjoint of temp.py:57-139).
 //
-// Mapping (wave64): workgroup = (batch, direction-group) x CW channels; wavefront = 16 channels;
-//   lane = (state group g = lane / 16, channel c = lane % 16); each lane carries 4 of the 16 states.
-//   -> sums over the 16 channels of a wave (dB, dC) are DPP row reductions,
-//      sums over the 4 state groups (du, ddelta) are two cross-row exchanges.
-// Per tile of 64 steps (processed last tile first), per sub-tile of 16 steps (last first):
-//   reload the state checkpoint the forward kernel saved at the sub-tile start (x_chk, every 16 steps),
-//   recompute the 16 states x_t into registers, then run the adjoint recurrence backwards:
-//     gx_t = C_t g_t + a_{t+1} gx_{t+1};  dC_t += g_t x_t;  dB_t += gx_t dl_t u_t;
-//     ddl_t = sum_n gx_t (x_{t-1} a_t A_n + B_t u_t);  du_t = sum_n gx_t dl_t B_t + D g_t;
-//     dA_n += gx_t x_{t-1} a_t dl_t
-//   dB/dC: wave-reduced in registers, accumulated across the workgroup's waves in LDS (ds_add_f32),
-//   stored once per tile (plain store when the workgroup owns the whole group, atomics otherwise).
+// Mapping (wave64): workgroup = one (batch, direction) x up to 8 waves; wavefront = 16 channels;
+//   lane = (state group g = lane / 16, channel c = lane % 16), 4 of the 16 states per lane.
+//   -> sums over the 16 channels of a wave (dB, dC) stay inside a 16-lane DPP row,
+//      sums over the 4 state groups (du, ddelta) are two permlane swaps.
+// Tiles of 32 steps, last tile first; per 16-step sub-tile (last first): start from the state checkpoint the
+// forward kernel wrote (x_chk, every 16 steps), recompute the 16 states into registers, then run the adjoint
+// recurrence backwards with 11 VALU + 1 v_exp_f32 per state-step:
+//     b = dlu*B;  gxt = C*g + gx;  w = x - b (= a*x_prev);  t2 = gxt*w;  dA += t2*dl;  s1 += t2*A;  s2 += gxt*B;
+//     dC_part = g*x;  dB_part = gxt*dlu;  gx = a*gxt              [ddelta' = s1 + u*s2,  du = dl*s2 + D*g]
+// dB/dC: an 8-value halving butterfly inside each 16-lane row (22 DPP ops per step instead of 32) leaves one sum
+// per lane, one ds_add_f32 per step accumulates the workgroup's waves in LDS; the accumulators are double
+// buffered and flushed one tile later, so the whole tile loop has ONE barrier per tile.
+// Global traffic uses bounds-checked buffer descriptors (mm_common.h) and a register prefetch of the next
+// tile; reversed directions / shared u blocks as in the forward kernel (include/medmamba_hip.h).
 #include "mm_common.h"
 #include "medmamba_hip.h"
 
@@ -37,60 +39,45 @@ struct BwdParams {
   float* __restrict__ dD;
   float* __restrict__ dbias;
   int64_t u_sb, u_sd, d_sb, d_sd, B_sb, B_sg, B_sn, C_sb, C_sg, C_sn;
-  int dim, L, G, H, CW, ncw, ntiles, nchk, softplus;
+  int dim, L, G, H, CW, ncw, ntiles, nchk;
   int ug;                   // channel blocks in u / dout
   unsigned u_map, rev_mask; // block of group g = (u_map >> 4g) & 15; bit g of rev_mask: group g runs backwards
 };
 
-// Time-ordered quad (time slots t..t+3) of the row at `row`; rev: slot t is memory position L-1-t.
-template <bool VEC>
-__device__ __forceinline__ float4 load4(const float* __restrict__ row, int t, int L, bool rev = false) {
-  if constexpr (VEC) {
-    if (t >= L) return make_float4(0.f, 0.f, 0.f, 0.f);
-    const float4 v = *reinterpret_cast<const float4*>(row + (rev ? L - 4 - t : t));
-    return rev ? make_float4(v.w, v.z, v.y, v.x) : v;
-  } else {
-    float4 v;
-    v.x = t + 0 < L ? row[rev ? L - 1 - t : t] : 0.f;
-    v.y = t + 1 < L ? row[rev ? L - 2 - t : t + 1] : 0.f;
-    v.z = t + 2 < L ? row[rev ? L - 3 - t : t + 2] : 0.f;
-    v.w = t + 3 < L ? row[rev ? L - 4 - t : t + 3] : 0.f;
-    return v;
-  }
-}
-template <bool VEC>
-__device__ __forceinline__ void store4(float* __restrict__ row, int t, int L, float4 v, bool rev = false) {
-  if constexpr (VEC) {
-    if (t < L) *reinterpret_cast<float4*>(row + (rev ? L - 4 - t : t)) = rev ? make_float4(v.w, v.z, v.y, v.x) : v;
-  } else {
-    if (t + 0 < L) row[rev ? L - 1 - t : t] = v.x;
-    if (t + 1 < L) row[rev ? L - 2 - t : t + 1] = v.y;
-    if (t + 2 < L) row[rev ? L - 3 - t : t + 2] = v.z;
-    if (t + 3 < L) row[rev ? L - 4 - t : t + 3] = v.w;
-  }
-}
 __device__ __forceinline__ float f4get(const float4& v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
 
-constexpr int NS = 4;    // states per lane
-constexpr int CH = 16;   // channels per wave
-constexpr int NLD = 4;   // float4 row-loads per lane per tensor per tile
+constexpr int NS = 4;            // states per lane
+constexpr int CH = 16;           // channels per wave
+constexpr int T = 32;            // steps per tile
+constexpr int TS = T + 4;        // LDS row stride (floats)
+constexpr int QL = T / 4;        // float4 columns per row = 8
+constexpr int RPI = kWave / QL;  // rows per load instruction = 8
+constexpr int NLD = CH / RPI;    // row-loads per lane per tensor per tile = 2
+constexpr int NSUB = T / kChunk; // 16-step sub-tiles per tile = 2
 
-template <bool VEC>
+constexpr int DPP_ROW_ROR8_ = 0x128;
+
+// keep + (send of the DPP partner lane)
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float keep, float send) { return keep + dpp_f<CTRL>(send); }
+
+template <bool VEC, bool SP>
 __global__ __launch_bounds__(512) void scan_bwd_kernel(const BwdParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x;
+  const int tid = threadIdx.x, lane = tid & 63, nthreads = blockDim.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int cw = blockIdx.x % p.ncw;
   const int bk = blockIdx.x / p.ncw;
   const int grp = bk % p.G, b = bk / p.G;
   const int ugrp = p.ug < p.G ? (int)((p.u_map >> (4 * grp)) & 15) : grp;
   const bool rev = grp < 32 && ((p.rev_mask >> grp) & 1);
 
-  float* sBC = smem;                                   // [2][16][kTileStride]   B, C tile
-  float* sAcc = smem + 2 * kNState * kTileStride;      // [2][16][kTileStride]   dB, dC accumulators
-  float* wl = smem + 4 * kNState * kTileStride + wave * (3 * CH * kTileStride);
+  float* sBC = smem;                                   // [2 buf][2][16][TS]   B, C tiles
+  float* sAcc = smem + 2 * 2 * kNState * TS;           // [2 buf][2][16][TS]   dB, dC accumulators
+  float* wl = smem + 4 * 2 * kNState * TS + wave * (3 * CH * TS);
   float* s_u = wl;                                     // u      -> du   (in place)
-  float* s_dl = wl + CH * kTileStride;                 // delta' -> ddl  (in place)
-  float* s_g = wl + 2 * CH * kTileStride;              // dout
+  float* s_dl = wl + CH * TS;                          // delta' -> ddelta' (in place)
+  float* s_g = wl + 2 * CH * TS;                       // dout
 
   // ---- recurrence identity
   const int g = lane >> 4, c = lane & 15;
@@ -106,92 +93,148 @@ __global__ __launch_bounds__(512) void scan_bwd_kernel(const BwdParams p) {
     gx[j] = 0.f;
   }
   const float Dc = p.D ? p.D[d] : 0.f;
+  const float* chk_base = p.x_chk + ((int64_t)b * p.dim + d) * p.nchk * kNState + g * NS;
+  // which of the 8 reduced dB/dC sums this lane ends up with (butterfly below): idx = 4*bit2 + 2*bit0 + bit1
+  const int ridx = ((c >> 2) & 1) * 4 + (c & 1) * 2 + ((c >> 1) & 1);
+  float* acc_lane = sAcc + ((ridx >> 2) * kNState + g * NS + (ridx & 3)) * TS;   // + buf*2*16*TS + t
 
-  // ---- staging identity
-  const int r = lane >> 4, q = lane & 15;
-  int64_t uoff[NLD], doff[NLD], ooff[NLD], goff[NLD];
-  float bv[NLD], dDacc[NLD], dbacc[NLD];
+  // ---- staging identity: lane -> (row r of an 8-row group, float4 column q)
+  const int r = lane / QL, q = lane % QL;
+  const int hc0 = cw * p.CW + wave * CH + r;
+  const int d0 = grp * p.H + cw * p.CW + wave * CH;            // first channel of this wave (uniform)
+  const int d0u = ugrp * p.H + cw * p.CW + wave * CH;
+  const rsrc_t ru = make_rsrc(p.u + b * p.u_sb + d0u * p.u_sd, ((int64_t)(p.ug * p.H - d0u - 1) * p.u_sd + p.L) * 4);
+  const rsrc_t rd = make_rsrc(p.delta + b * p.d_sb + d0 * p.d_sd, ((int64_t)(p.dim - d0 - 1) * p.d_sd + p.L) * 4);
+  const rsrc_t rg = make_rsrc(p.dout + ((int64_t)b * p.ug * p.H + d0u) * p.L, (int64_t)(p.ug * p.H - d0u) * p.L * 4);
+  const rsrc_t rdu = make_rsrc(p.du + ((int64_t)b * p.dim + d0) * p.L, (int64_t)(p.dim - d0) * p.L * 4);
+  const rsrc_t rdd = make_rsrc(p.ddelta + ((int64_t)b * p.dim + d0) * p.L, (int64_t)(p.dim - d0) * p.L * 4);
+  const rsrc_t rB = make_rsrc(p.B + b * p.B_sb + grp * p.B_sg, ((int64_t)(kNState - 1) * p.B_sn + p.L) * 4);
+  const rsrc_t rC = make_rsrc(p.C + b * p.C_sb + grp * p.C_sg, ((int64_t)(kNState - 1) * p.C_sn + p.L) * 4);
+  float* dBbase = p.dB + ((int64_t)b * p.G + grp) * kNState * p.L;
+  float* dCbase = p.dC + ((int64_t)b * p.G + grp) * kNState * p.L;
   bool rvalid[NLD];
+  int uoff[NLD], doff[NLD], ooff[NLD];
+  float bv[NLD], dDacc[NLD], dbacc[NLD];
 #pragma unroll
   for (int i = 0; i < NLD; ++i) {
-    const int hcc = cw * p.CW + wave * CH + 4 * i + r;
-    rvalid[i] = hcc < p.H;
-    const int dd = grp * p.H + (rvalid[i] ? hcc : 0);
-    const int ddu = ugrp * p.H + (rvalid[i] ? hcc : 0);          // channel inside the shared u / dout blocks
-    uoff[i] = b * p.u_sb + ddu * p.u_sd;
-    doff[i] = b * p.d_sb + dd * p.d_sd;
-    ooff[i] = ((int64_t)b * p.dim + dd) * p.L;
-    goff[i] = ((int64_t)b * p.ug * p.H + ddu) * p.L;
+    rvalid[i] = hc0 + RPI * i < p.H;
+    const int dd = grp * p.H + (rvalid[i] ? hc0 + RPI * i : 0);
     bv[i] = p.bias ? p.bias[dd] : 0.f;
+    uoff[i] = (int)((r + RPI * i) * p.u_sd) * 4;
+    doff[i] = (int)((r + RPI * i) * p.d_sd) * 4;
+    ooff[i] = ((r + RPI * i) * p.L) * 4;
     dDacc[i] = 0.f;
     dbacc[i] = 0.f;
   }
-  const float* Bbase = p.B + b * p.B_sb + grp * p.B_sg;
-  const float* Cbase = p.C + b * p.C_sb + grp * p.C_sg;
-  float* dBbase = p.dB + ((int64_t)b * p.G + grp) * kNState * p.L;
-  float* dCbase = p.dC + ((int64_t)b * p.G + grp) * kNState * p.L;
+  // B/C tile = 2 x 16 rows x 8 quads = 256 float4, spread over the workgroup's threads (one per thread for >= 4 waves)
+  const int bc_which = (tid >> 7) & 1, bc_n = (tid >> 3) & 15, bc_q = tid & 7;
+  const bool bc_mine = tid < 256;
+  const int bc_off = (int)(bc_n * (bc_which ? p.C_sn : p.B_sn)) * 4;
+
+  float4 pu[NLD], pd[NLD], pg[NLD], pbc;
+  auto issue_loads = [&](int t0) {
+    const int t = t0 + 4 * q;
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      pu[i] = load_quad<VEC>(ru, uoff[i], t, p.L, rev, rvalid[i]);
+      pd[i] = load_quad<VEC>(rd, doff[i], t, p.L, rev, rvalid[i]);
+      pg[i] = load_quad<VEC>(rg, ooff[i], t, p.L, rev, rvalid[i]);
+    }
+    if (nthreads >= 256) pbc = load_quad<VEC>(bc_which ? rC : rB, bc_off, t0 + 4 * bc_q, p.L, rev, bc_mine);
+  };
+
+  // flush one accumulator buffer (tile starting at t0) to global and clear it
+  auto flush_acc = [&](int buf, int t0) {
+    for (int idx = tid; idx < 256; idx += nthreads) {
+      const int which = idx >> 7, n = (idx >> 3) & 15, qq = idx & 7;
+      float* a = sAcc + ((buf * 2 + which) * kNState + n) * TS + 4 * qq;
+      const float4 v = *reinterpret_cast<const float4*>(a);
+      *reinterpret_cast<float4*>(a) = make_float4(0.f, 0.f, 0.f, 0.f);
+      float* dst = (which ? dCbase : dBbase) + (int64_t)n * p.L;
+      const int t = t0 + 4 * qq;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int te = t + e;
+        if (te < p.L) {
+          float* pdst = dst + (rev ? p.L - 1 - te : te);
+          if (p.ncw == 1) *pdst = f4get(v, e); else atomicAdd(pdst, f4get(v, e));
+        }
+      }
+    }
+  };
+
+  for (int idx = tid; idx < 2 * 2 * kNState * TS; idx += nthreads) sAcc[idx] = 0.f;
+
+  issue_loads((p.ntiles - 1) * T);
+  // checkpoint prefetch for the first sub-tile to be processed (the state BEFORE sub-tile `sub` of `tile`)
+  auto chk_index = [&](int tile, int sub) { return tile * NSUB + sub - 1; };
+  float4 x0n = make_float4(0.f, 0.f, 0.f, 0.f);
+  {
+    const int tl0 = min(T, p.L - (p.ntiles - 1) * T);
+    const int ci = chk_index(p.ntiles - 1, (tl0 + kChunk - 1) / kChunk - 1);
+    if (ci >= 0 && cvalid) x0n = *reinterpret_cast<const float4*>(chk_base + (int64_t)ci * kNState);
+  }
 
   for (int tile = p.ntiles - 1; tile >= 0; --tile) {
-    const int t0 = tile * kTile;
-    float4 sig[NLD];
-    // ---- phase 1: global -> LDS
+    const int t0 = tile * T;
+    const int buf = (p.ntiles - 1 - tile) & 1;
+    // ---- phase 1: registers -> LDS
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
       const int t = t0 + 4 * q;
-      const bool ok = rvalid[i];
-      const float4 zu = make_float4(0.f, 0.f, 0.f, 0.f);
-      const float4 vu = ok ? load4<VEC>(p.u + uoff[i], t, p.L, rev) : zu;
-      const float4 vd = ok ? load4<VEC>(p.delta + doff[i], t, p.L, rev) : zu;
-      const float4 vg = ok ? load4<VEC>(p.dout + goff[i], t, p.L, rev) : zu;
       float4 dl;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float raw = f4get(vd, e) + bv[i];
-        const bool in = ok && (t + e < p.L);
-        float v = p.softplus ? softplus_f(raw) : raw;
+        const float raw = f4get(pd[i], e) + bv[i];
+        const bool in = rvalid[i] && (t + e < p.L);
+        const float v = SP ? softplus_f(raw) : raw;
         (&dl.x)[e] = in ? v : 0.f;
-        (&sig[i].x)[e] = p.softplus ? (raw > 20.f ? 1.f : sigmoid_f(raw)) : 1.f;
-        dDacc[i] += f4get(vg, e) * f4get(vu, e);
+        dDacc[i] = fmaf(f4get(pg[i], e), f4get(pu[i], e), dDacc[i]);
       }
-      const int off = (4 * i + r) * kTileStride + 4 * q;
-      *reinterpret_cast<float4*>(s_u + off) = vu;
+      const int off = (RPI * i + r) * TS + 4 * q;
+      *reinterpret_cast<float4*>(s_u + off) = pu[i];
       *reinterpret_cast<float4*>(s_dl + off) = dl;
-      *reinterpret_cast<float4*>(s_g + off) = vg;
+      *reinterpret_cast<float4*>(s_g + off) = pg[i];
     }
-    for (int idx = tid; idx < 512; idx += nthreads) {
-      const int which = idx >> 8, n = (idx >> 4) & 15, qq = idx & 15;
-      const float* src = which ? Cbase + n * p.C_sn : Bbase + n * p.B_sn;
-      const int o = (which * kNState + n) * kTileStride + 4 * qq;
-      *reinterpret_cast<float4*>(sBC + o) = load4<VEC>(src, t0 + 4 * qq, p.L, rev);
-      *reinterpret_cast<float4*>(sAcc + o) = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (nthreads >= 256) {
+      if (bc_mine) *reinterpret_cast<float4*>(sBC + ((buf * 2 + bc_which) * kNState + bc_n) * TS + 4 * bc_q) = pbc;
+    } else {   // fewer than 4 waves (tiny problems): every thread stages several quads, no prefetch
+      for (int idx = tid; idx < 256; idx += nthreads) {
+        const int w_ = (idx >> 7) & 1, n_ = (idx >> 3) & 15, q_ = idx & 7;
+        *reinterpret_cast<float4*>(sBC + ((buf * 2 + w_) * kNState + n_) * TS + 4 * q_) =
+            load_quad<VEC>(w_ ? rC : rB, (int)(n_ * (w_ ? p.C_sn : p.B_sn)) * 4, t0 + 4 * q_, p.L, rev, true);
+      }
     }
-    __syncthreads();
+    if (tile > 0) issue_loads(t0 - T);
+    __syncthreads();                                       // the ONE barrier per tile
+    if (tile < p.ntiles - 1) flush_acc(buf ^ 1, t0 + T);   // everybody has finished adding to the previous tile
 
     // ---- phase 2: sub-tiles of 16 steps, last first
-    const int tlen = min(kTile, p.L - t0);
+    const int tlen = min(T, p.L - t0);
     const int nsub = (tlen + kChunk - 1) / kChunk;
-    const float* sB = sBC + (g * NS) * kTileStride;
-    const float* sC = sBC + (kNState + g * NS) * kTileStride;
+    const float* sB = sBC + ((buf * 2 + 0) * kNState + g * NS) * TS;
+    const float* sC = sBC + ((buf * 2 + 1) * kNState + g * NS) * TS;
+    float* accb = acc_lane + buf * 2 * kNState * TS;
     for (int sub = nsub - 1; sub >= 0; --sub) {
-      const int ts = sub * kChunk;                  // offset inside the tile
-      const int chunk = (t0 >> 4) + sub;            // global chunk index
-      float xs[kChunk][NS], x0[NS];
-      if (chunk > 0 && cvalid) {
-        const float4 v = *reinterpret_cast<const float4*>(
-            p.x_chk + (((int64_t)b * p.dim + d) * p.nchk + (chunk - 1)) * kNState + g * NS);
-        x0[0] = v.x; x0[1] = v.y; x0[2] = v.z; x0[3] = v.w;
-      } else {
-        x0[0] = x0[1] = x0[2] = x0[3] = 0.f;
+      const int ts = sub * kChunk;
+      float xs[kChunk][NS];
+      const float x0[NS] = {x0n.x, x0n.y, x0n.z, x0n.w};
+      {   // prefetch the checkpoint of the NEXT sub-tile to be processed
+        int nt = tile, ns_ = sub - 1;
+        if (ns_ < 0) { nt = tile - 1; ns_ = NSUB - 1; }
+        const int ci = chk_index(nt, ns_);
+        x0n = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (nt >= 0 && ci >= 0 && cvalid) x0n = *reinterpret_cast<const float4*>(chk_base + (int64_t)ci * kNState);
       }
       // forward recompute of the 16 states
 #pragma unroll
       for (int tq = 0; tq < 4; ++tq) {
         const int to = ts + 4 * tq;
-        const float4 dl4 = *reinterpret_cast<const float4*>(s_dl + c * kTileStride + to);
-        const float4 u4 = *reinterpret_cast<const float4*>(s_u + c * kTileStride + to);
+        const float4 dl4 = *reinterpret_cast<const float4*>(s_dl + c * TS + to);
+        const float4 u4 = *reinterpret_cast<const float4*>(s_u + c * TS + to);
         float4 Bv[NS];
 #pragma unroll
-        for (int j = 0; j < NS; ++j) Bv[j] = *reinterpret_cast<const float4*>(sB + j * kTileStride + to);
+        for (int j = 0; j < NS; ++j) Bv[j] = *reinterpret_cast<const float4*>(sB + j * TS + to);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float dl = f4get(dl4, e), dlu = dl * f4get(u4, e);
@@ -207,14 +250,14 @@ __global__ __launch_bounds__(512) void scan_bwd_kernel(const BwdParams p) {
 #pragma unroll
       for (int tq = 3; tq >= 0; --tq) {
         const int to = ts + 4 * tq;
-        const float4 dl4 = *reinterpret_cast<const float4*>(s_dl + c * kTileStride + to);
-        const float4 u4 = *reinterpret_cast<const float4*>(s_u + c * kTileStride + to);
-        const float4 g4 = *reinterpret_cast<const float4*>(s_g + c * kTileStride + to);
+        const float4 dl4 = *reinterpret_cast<const float4*>(s_dl + c * TS + to);
+        const float4 u4 = *reinterpret_cast<const float4*>(s_u + c * TS + to);
+        const float4 g4 = *reinterpret_cast<const float4*>(s_g + c * TS + to);
         float4 Bv[NS], Cv[NS];
 #pragma unroll
         for (int j = 0; j < NS; ++j) {
-          Bv[j] = *reinterpret_cast<const float4*>(sB + j * kTileStride + to);
-          Cv[j] = *reinterpret_cast<const float4*>(sC + j * kTileStride + to);
+          Bv[j] = *reinterpret_cast<const float4*>(sB + j * TS + to);
+          Cv[j] = *reinterpret_cast<const float4*>(sC + j * TS + to);
         }
         float4 du4, ddl4;
 #pragma unroll
@@ -222,77 +265,72 @@ __global__ __launch_bounds__(512) void scan_bwd_kernel(const BwdParams p) {
           const int tt = 4 * tq + e;
           const float dl = f4get(dl4, e), ut = f4get(u4, e), gt = f4get(g4, e);
           const float dlu = dl * ut;
-          float ddl = 0.f, duu = 0.f;
-          float dBv[NS], dCv[NS];
+          float s1 = 0.f, s2 = 0.f;
+          float v[8];                                  // dB partials [0..3], dC partials [4..7]
 #pragma unroll
           for (int j = 0; j < NS; ++j) {
             const float Bn = f4get(Bv[j], e), Cn = f4get(Cv[j], e);
-            const float xprev = tt == 0 ? x0[j] : xs[tt - 1][j];
+            const float xc = xs[tt][j];
             const float gxt = fmaf(Cn, gt, gx[j]);
-            const float a = __builtin_amdgcn_exp2f(dl * A2[j]);
-            dCv[j] = gt * xs[tt][j];
-            dBv[j] = gxt * dlu;
-            const float t2 = gxt * xprev * a;
-            ddl = fmaf(t2, An[j], ddl);
-            ddl = fmaf(gxt, Bn * ut, ddl);
-            duu = fmaf(gxt, dl * Bn, duu);
+            const float w = fmaf(-dlu, Bn, xc);        // = a_t * x_{t-1}
+            const float t2 = gxt * w;
             dAacc[j] = fmaf(t2, dl, dAacc[j]);
-            gx[j] = a * gxt;
+            s1 = fmaf(t2, An[j], s1);
+            s2 = fmaf(gxt, Bn, s2);
+            v[4 + j] = gt * xc;
+            v[j] = gxt * dlu;
+            gx[j] = __builtin_amdgcn_exp2f(dl * A2[j]) * gxt;   // a_t recomputed: keeping 64 more VGPRs would spill
           }
-          // sums over the 4 state groups (rows of 16 lanes)
-          ddl += __shfl_xor(ddl, 16); ddl += __shfl_xor(ddl, 32);
-          duu += __shfl_xor(duu, 16); duu += __shfl_xor(duu, 32);
-          (&ddl4.x)[e] = ddl;
-          (&du4.x)[e] = fmaf(Dc, gt, duu);
-          // sums over the wave's 16 channels, then one LDS atomic per (n, t) per wave
+          // (ddelta', du) partials of this state group -> sum over the 4 rows with two permlane swaps:
+          // after swap32+add the lower half holds sum(pa), the upper half sum(pb); swap16 finishes both.
+          float pa = fmaf(ut, s2, s1), pb = dl * s2;
+          {
+            const auto r32 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, pa), __builtin_bit_cast(unsigned, pb), false, false);
+            const unsigned r0 = r32[0], r1 = r32[1];
+            const float s = __builtin_bit_cast(float, r0) + __builtin_bit_cast(float, r1);
+            const auto r16 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, s), __builtin_bit_cast(unsigned, s), false, false);
+            const unsigned q0 = r16[0], q1 = r16[1];
+            pa = __builtin_bit_cast(float, q0) + __builtin_bit_cast(float, q1);   // rows 0,1: ddelta'   rows 2,3: du - D*g
+          }
+          // d softplus / d raw = sigmoid(raw) = 1 - exp(-delta')  (series for tiny delta' keeps it relative-accurate)
+          const float sg = SP ? (dl < 9.765625e-4f ? dl * (1.f - 0.5f * dl) : 1.f - __builtin_amdgcn_exp2f(-dl * kLog2e)) : 1.f;
+          (&ddl4.x)[e] = pa * sg;
+          (&du4.x)[e] = fmaf(Dc, gt, pa);
+          // dB/dC: 8 values x 16 lanes -> one value per lane (halving butterfly), then one LDS atomic per lane
+          {
+            const bool b2 = (c >> 2) & 1, b0 = c & 1, b1 = (c >> 1) & 1;
+            float w4[4], w2[2];
 #pragma unroll
-          for (int j = 0; j < NS; ++j) {
-            const float sb = group_sum<16>(dBv[j]);
-            const float sc = group_sum<16>(dCv[j]);
-            if (c == 0) {
-              atomicAdd(sAcc + (g * NS + j) * kTileStride + to + e, sb);
-              atomicAdd(sAcc + (kNState + g * NS + j) * kTileStride + to + e, sc);
-            }
+            for (int k = 0; k < 4; ++k)               // pair i <-> i^7 (row_half_mirror); bit2 decides the kept half
+              w4[k] = dpp_add<DPP_ROW_HALF_MIRROR>(b2 ? v[4 + k] : v[k], b2 ? v[k] : v[4 + k]);
+#pragma unroll
+            for (int k = 0; k < 2; ++k)               // pair i <-> i^1; bit0 decides
+              w2[k] = dpp_add<DPP_QUAD_XOR1>(b0 ? w4[2 + k] : w4[k], b0 ? w4[k] : w4[2 + k]);
+            float w1 = dpp_add<DPP_QUAD_XOR2>(b1 ? w2[1] : w2[0], b1 ? w2[0] : w2[1]);   // pair i <-> i^2; bit1 decides
+            w1 += dpp_f<DPP_ROW_ROR8_>(w1);           // pair i <-> i^8
+            if (c < 8) atomicAdd(accb + to + e, w1);
           }
         }
-        if (g == 0) {
-          *reinterpret_cast<float4*>(s_u + c * kTileStride + to) = du4;
-          *reinterpret_cast<float4*>(s_dl + c * kTileStride + to) = ddl4;
-        }
+        if (g == 0) *reinterpret_cast<float4*>(s_dl + c * TS + to) = ddl4;
+        if (g == 2) *reinterpret_cast<float4*>(s_u + c * TS + to) = du4;
       }
     }
-    __syncthreads();
 
-    // ---- phase 3: LDS -> global
+    // ---- phase 3: private LDS -> global
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
       const int t = t0 + 4 * q;
-      const int off = (4 * i + r) * kTileStride + 4 * q;
+      const int off = (RPI * i + r) * TS + 4 * q;
       const float4 vdu = *reinterpret_cast<const float4*>(s_u + off);
-      float4 vdd = *reinterpret_cast<const float4*>(s_dl + off);
-      vdd.x *= sig[i].x; vdd.y *= sig[i].y; vdd.z *= sig[i].z; vdd.w *= sig[i].w;
-      if (rvalid[i]) {
-        store4<VEC>(p.du + ooff[i], t, p.L, vdu, rev);
-        store4<VEC>(p.ddelta + ooff[i], t, p.L, vdd, rev);
+      const float4 vdd = *reinterpret_cast<const float4*>(s_dl + off);
+      store_quad<VEC>(rdu, ooff[i], t, p.L, rev, rvalid[i], vdu);
+      store_quad<VEC>(rdd, ooff[i], t, p.L, rev, rvalid[i], vdd);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) dbacc[i] += (t + e < p.L) ? f4get(vdd, e) : 0.f;
-      }
+      for (int e = 0; e < 4; ++e) dbacc[i] += (rvalid[i] && t + e < p.L) ? f4get(vdd, e) : 0.f;
     }
-    for (int idx = tid; idx < 512; idx += nthreads) {
-      const int which = idx >> 8, n = (idx >> 4) & 15, qq = idx & 15;
-      const float4 v = *reinterpret_cast<const float4*>(sAcc + (which * kNState + n) * kTileStride + 4 * qq);
-      float* dst = (which ? dCbase : dBbase) + (int64_t)n * p.L;
-      const int t = t0 + 4 * qq;
-      if (p.ncw == 1) {
-        store4<VEC>(dst, t, p.L, v, rev);
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (t + e < p.L) atomicAdd(dst + (rev ? p.L - 1 - t - e : t + e), f4get(v, e));
-      }
-    }
-    __syncthreads();
   }
+  __syncthreads();
+  flush_acc((p.ntiles - 1) & 1, 0);               // accumulators of the last processed tile (tile 0)
 
   // ---- per-channel parameter gradients: reduce in the wave, one atomic per value
   if (cvalid) {
@@ -301,10 +339,12 @@ __global__ __launch_bounds__(512) void scan_bwd_kernel(const BwdParams p) {
   }
 #pragma unroll
   for (int i = 0; i < NLD; ++i) {
-    const float sD = group_sum<16>(dDacc[i]);
-    const float sb = group_sum<16>(dbacc[i]);
+    // the 8 lanes (q) that share a row are 8 consecutive lanes: xor 1, xor 2 and i <-> 7-i cover them
+    float sD = dDacc[i], sb = dbacc[i];
+    sD += dpp_f<DPP_QUAD_XOR1>(sD); sD += dpp_f<DPP_QUAD_XOR2>(sD); sD += dpp_f<DPP_ROW_HALF_MIRROR>(sD);
+    sb += dpp_f<DPP_QUAD_XOR1>(sb); sb += dpp_f<DPP_QUAD_XOR2>(sb); sb += dpp_f<DPP_ROW_HALF_MIRROR>(sb);
     if (q == 0 && rvalid[i]) {
-      const int dd = grp * p.H + cw * p.CW + wave * CH + 4 * i + r;
+      const int dd = grp * p.H + hc0 + RPI * i;
       if (p.dD) atomicAdd(p.dD + dd, sD);
       if (p.dbias) atomicAdd(p.dbias + dd, sb);
     }
@@ -312,6 +352,14 @@ __global__ __launch_bounds__(512) void scan_bwd_kernel(const BwdParams p) {
 }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+template <bool VEC, bool SP>
+int launch(const BwdParams& p, int nblocks, int waves, hipStream_t stream) {
+  const size_t lds = sizeof(float) * (4 * 2 * kNState * TS + (size_t)waves * 3 * CH * TS);
+  if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)scan_bwd_kernel<VEC, SP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((scan_bwd_kernel<VEC, SP>), dim3(nblocks), dim3(waves * 64), lds, stream, p);
+  return (int)hipGetLastError();
+}
 }  // namespace
 
 namespace mm {
@@ -324,33 +372,27 @@ int scan_bwd_launch(const mm_scan_args* a, hipStream_t stream) {
   p.u_sb = a->u_sb; p.u_sd = a->u_sd; p.d_sb = a->delta_sb; p.d_sd = a->delta_sd;
   p.B_sb = a->B_sb; p.B_sg = a->B_sg; p.B_sn = a->B_sn; p.C_sb = a->C_sb; p.C_sg = a->C_sg; p.C_sn = a->C_sn;
   p.dim = a->dim; p.L = a->L; p.G = a->G; p.H = a->dim / a->G;
-  p.ntiles = (a->L + kTile - 1) / kTile;
+  p.ntiles = (a->L + T - 1) / T;
   p.nchk = (a->L + kChunk - 1) / kChunk;
-  p.softplus = a->delta_softplus;
   const bool shared = a->u_groups > 0 && a->u_groups < a->G;
   p.ug = shared ? a->u_groups : a->G;
   p.u_map = shared ? a->u_map : 0x76543210u;
   p.rev_mask = a->rev_mask;
+  const int64_t span = (int64_t)a->dim * (a->u_sd > a->L ? a->u_sd : a->L) * 4;
+  if (span >= 0x7ffffff0ll || (int64_t)kNState * a->B_sn * 4 >= 0x7ffffff0ll) return MM_ERR_UNSUPPORTED;
   const int waves_needed = (p.H + CH - 1) / CH;
-  const int ncw0 = (waves_needed + 7) / 8;                   // <= 8 waves (~122 KB LDS) per workgroup
+  const int ncw0 = (waves_needed + 7) / 8;                   // <= 8 waves per workgroup
   const int waves = (waves_needed + ncw0 - 1) / ncw0;
   p.CW = waves * CH;
   p.ncw = (p.H + p.CW - 1) / p.CW;
   const int nblocks = a->batch * a->G * p.ncw;
-  const size_t lds = sizeof(float) * (4 * kNState * kTileStride + (size_t)waves * 3 * CH * kTileStride);
   const bool vec = (a->L % 4 == 0) && aligned16(a->u) && aligned16(a->delta) && aligned16(a->B) && aligned16(a->C) &&
-                   aligned16(a->dout) && aligned16(a->du) && aligned16(a->ddelta) && aligned16(a->dB) &&
-                   aligned16(a->dC) && a->u_sb % 4 == 0 && a->u_sd % 4 == 0 && a->delta_sb % 4 == 0 &&
-                   a->delta_sd % 4 == 0 && a->B_sb % 4 == 0 && a->B_sg % 4 == 0 && a->B_sn % 4 == 0 &&
-                   a->C_sb % 4 == 0 && a->C_sg % 4 == 0 && a->C_sn % 4 == 0;
-  if (vec) {
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)scan_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(scan_bwd_kernel<true>, dim3(nblocks), dim3(waves * 64), lds, stream, p);
-  } else {
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)scan_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(scan_bwd_kernel<false>, dim3(nblocks), dim3(waves * 64), lds, stream, p);
-  }
-  return (int)hipGetLastError();
+                   aligned16(a->dout) && aligned16(a->du) && aligned16(a->ddelta) && a->u_sb % 4 == 0 &&
+                   a->u_sd % 4 == 0 && a->delta_sb % 4 == 0 && a->delta_sd % 4 == 0 && a->B_sb % 4 == 0 &&
+                   a->B_sg % 4 == 0 && a->B_sn % 4 == 0 && a->C_sb % 4 == 0 && a->C_sg % 4 == 0 && a->C_sn % 4 == 0;
+  const bool sp = a->delta_softplus != 0;
+  if (vec) return sp ? launch<true, true>(p, nblocks, waves, stream) : launch<true, false>(p, nblocks, waves, stream);
+  return sp ? launch<false, true>(p, nblocks, waves, stream) : launch<false, false>(p, nblocks, waves, stream);
 }
 
 }  // namespace mm

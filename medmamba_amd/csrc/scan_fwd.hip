@@ -49,61 +49,6 @@ struct FwdParams {
   int dbg;   // timing-only ablation bits (bench diagnostics; results are wrong when set): 1 no y store, 2 no recurrence
 };
 
-using rsrc_t = __amdgpu_buffer_rsrc_t;
-typedef unsigned v4u __attribute__((ext_vector_type(4)));
-typedef float v4f __attribute__((ext_vector_type(4)));
-// NOTE: never __builtin_bit_cast a single ext-vector ELEMENT (v.x): hipcc 7.2 miscompiles it to element 0;
-// bit_cast the whole vector and then take components.
-constexpr int kOOB = 0x7fffffff;   // voffset that always fails the range check
-
-__device__ __forceinline__ rsrc_t make_rsrc(const void* base, int64_t bytes) {
-  const int64_t capped = bytes > 0x7ffffff0ll ? 0x7ffffff0ll : bytes;
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)capped, 0x00020000);
-}
-
-// Time-ordered values of time slots t..t+3 of the row that starts at byte offset `row` of descriptor r.
-// rev: slot t lives at memory position L-1-t (the row is walked backwards; nothing is ever flipped in memory).
-// VEC (L % 4 == 0, 16-B aligned rows): one dwordx4, a quad is entirely inside or outside the row.
-template <bool VEC>
-__device__ __forceinline__ float4 load_quad(rsrc_t r, int row, int t, int L, bool rev, bool rowok) {
-  if constexpr (VEC) {
-    const bool ok = rowok && t < L;
-    const int pos = rev ? L - 4 - t : t;
-    const v4u v = __builtin_amdgcn_raw_buffer_load_b128(r, ok ? row + pos * 4 : kOOB, 0, 0);
-    const v4f f = __builtin_bit_cast(v4f, v);
-    return rev ? make_float4(f.w, f.z, f.y, f.x) : make_float4(f.x, f.y, f.z, f.w);
-  } else {
-    float o[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int te = t + e;
-      const int pos = rev ? L - 1 - te : te;
-      const unsigned a = __builtin_amdgcn_raw_buffer_load_b32(r, (rowok && te < L) ? row + pos * 4 : kOOB, 0, 0);
-      o[e] = __builtin_bit_cast(float, a);
-    }
-    return make_float4(o[0], o[1], o[2], o[3]);
-  }
-}
-
-template <bool VEC>
-__device__ __forceinline__ void store_quad(rsrc_t r, int row, int t, int L, bool rev, bool rowok, float4 v) {
-  if constexpr (VEC) {
-    const bool ok = rowok && t < L;
-    const int pos = rev ? L - 4 - t : t;
-    const v4f f = rev ? (v4f){v.w, v.z, v.y, v.x} : (v4f){v.x, v.y, v.z, v.w};
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, f), r, ok ? row + pos * 4 : kOOB, 0, 0);
-  } else {
-    const float o[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int te = t + e;
-      const int pos = rev ? L - 1 - te : te;
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o[e]), r,
-                                            (rowok && te < L) ? row + pos * 4 : kOOB, 0, 0);
-    }
-  }
-}
-
 __device__ __forceinline__ float f4get(const float4& v, int i) {
   return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w;
 }
