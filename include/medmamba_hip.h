@@ -106,6 +106,43 @@ int mm_scan_bwd(const mm_scan_args* args, void* stream);
 /* checkpoint interval (steps) of x_chk */
 int mm_scan_chunk(void);
 
+/* Block glue of SS_Conv_SSM.forward (MedMamba.py:354-357 + channel_shuffle :308-320), one pass over HBM:
+ *   out[b,p,2i] = left[b,i,p] + inp[b,p,2i] ;  out[b,p,2i+1] = ssm[b,p,i] + inp[b,p,2i+1]
+ * left: conv-branch output NCHW (batch, C2, P); ssm: SS2D-branch output NHWC (batch, P, C2);
+ * inp, out: block input / output NHWC (batch, P, 2*C2); all contiguous fp32, P = H*W.
+ * Backward: dleft (batch, C2, P) and dssm (batch, P, C2) from dout (batch, P, 2*C2); d(inp) = dout. */
+int mm_shuffle_residual_fwd(const float* left, const float* ssm, const float* inp, float* out, int batch, int P, int C2,
+                            void* stream);
+int mm_shuffle_residual_bwd(const float* dout, float* dleft, float* dssm, int batch, int P, int C2, void* stream);
+
+/* ---- SS2D in channel-first planes (everything between in_proj and out_proj is (batch, channel, H*W)) ----------
+ * mm_dwconv_silu_cross_fwd: depthwise conv3x3 (pad 1) + bias + SiLU (MedMamba.py:153-162, 295) that writes the scan's
+ *   two input orders directly (replaces the permute of :294 and the stack/transpose of :256):
+ *   x planes (b,d) of H*W floats at x + b*x_sb + d*H*W; w (D,1,3,3); bias (D) or NULL;
+ *   u2 (batch, 2, D, H*W): u2[b,0,d,h*W+w] = u2[b,1,d,w*H+h] = silu(conv(x)[b,d,h,w] + bias[d]).
+ * mm_dwconv_silu_cross_bwd: du2 (batch,2,D,L) -> dx planes (batch stride dx_sb) and per-plane partial sums
+ *   ws[(b*D+d)*10 + (0..8: dW[kh][kw], 9: dbias)]  (the caller sums over b). */
+int mm_dwconv_silu_cross_fwd(const float* x, int64_t x_sb, const float* w, const float* bias, float* u2, int batch, int D,
+                             int H, int W, void* stream);
+int mm_dwconv_silu_cross_bwd(const float* du2, const float* x, int64_t x_sb, const float* w, const float* bias, float* dx,
+                             int64_t dx_sb, float* ws, int batch, int D, int H, int W, void* stream);
+/* cross-merge (MedMamba.py:282-286 + the 4-way sum of :298), all tensors in position order:
+ *   m[b,d,h*W+w] = out4[b,0,d,h*W+w] + out4[b,1,d,h*W+w] + out4[b,2,d,w*H+h] + out4[b,3,d,w*H+h]
+ *   (directions: row-major forward / backward, column-major forward / backward).  out4 (batch,4,D,L), m (batch,D,L). */
+int mm_cross_merge_fwd(const float* out4, float* m, int batch, int D, int H, int W, void* stream);
+/* dst[b,d,w*H+h] = src[b,d,h*W+w]; planes at base + b*sb + d*H*W (adjoint of the column-major half of the merge) */
+int mm_plane_transpose(const float* src, int64_t src_sb, float* dst, int64_t dst_sb, int batch, int D, int H, int W, void* stream);
+/* out_norm LayerNorm over the D channels (eps) + gate with SiLU(z) (MedMamba.py:300-301), channel-first:
+ *   y[b,d,p] = ((m[b,d,p]-mu[b,p])*rstd[b,p]*gamma[d]+beta[d]) * silu(z[b,d,p]);  m,y (batch,D,L); z planes with batch
+ *   stride z_sb; mu,rstd (batch,L) outputs.  Backward: dm (batch stride dm_sb), dz (batch stride dz_sb) and per-wave
+ *   partial sums ws[row*2*D + (0: dgamma, D: dbeta) + d] for row < mm_ln_gate_rows(batch, L) (the caller sums rows). */
+int mm_ln_gate_fwd(const float* m, const float* z, int64_t z_sb, const float* gamma, const float* beta, float eps, float* y,
+                   float* mu, float* rstd, int batch, int D, int L, void* stream);
+int mm_ln_gate_bwd(const float* dy, const float* m, const float* z, int64_t z_sb, const float* gamma, const float* beta,
+                   const float* mu, const float* rstd, float* dm, int64_t dm_sb, float* dz, int64_t dz_sb, float* ws, int batch,
+                   int D, int L, void* stream);
+int mm_ln_gate_rows(int batch, int L);
+
 int mm_abi_version(void);
 const char* mm_status_string(int status);
 

@@ -37,6 +37,18 @@ SYMBOLS = {
     "mm_status_string": (ctypes.c_char_p, [ctypes.c_int]),
     "mm_scan_fwd": (ctypes.c_int, [ctypes.POINTER(ScanArgs), ctypes.c_void_p]),
     "mm_scan_bwd": (ctypes.c_int, [ctypes.POINTER(ScanArgs), ctypes.c_void_p]),
+    "mm_shuffle_residual_fwd": (ctypes.c_int, [_f32p] * 4 + [ctypes.c_int] * 3 + [ctypes.c_void_p]),
+    "mm_dwconv_silu_cross_fwd": (ctypes.c_int, [_f32p, ctypes.c_int64, _f32p, _f32p, _f32p] + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
+    "mm_dwconv_silu_cross_bwd": (ctypes.c_int, [_f32p, _f32p, ctypes.c_int64, _f32p, _f32p, _f32p, ctypes.c_int64, _f32p]
+                                 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
+    "mm_cross_merge_fwd": (ctypes.c_int, [_f32p, _f32p] + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
+    "mm_plane_transpose": (ctypes.c_int, [_f32p, ctypes.c_int64, _f32p, ctypes.c_int64] + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
+    "mm_ln_gate_fwd": (ctypes.c_int, [_f32p, _f32p, ctypes.c_int64, _f32p, _f32p, ctypes.c_float, _f32p, _f32p, _f32p]
+                       + [ctypes.c_int] * 3 + [ctypes.c_void_p]),
+    "mm_ln_gate_bwd": (ctypes.c_int, [_f32p, _f32p, _f32p, ctypes.c_int64, _f32p, _f32p, _f32p, _f32p, _f32p, ctypes.c_int64,
+                                      _f32p, ctypes.c_int64, _f32p] + [ctypes.c_int] * 3 + [ctypes.c_void_p]),
+    "mm_ln_gate_rows": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
+    "mm_shuffle_residual_bwd": (ctypes.c_int, [_f32p] * 3 + [ctypes.c_int] * 3 + [ctypes.c_void_p]),
 }
 
 _lib = None

@@ -1,0 +1,468 @@
+// Block-level glue of SS_Conv_SSM on gfx950: pure data movement, fused so that every tensor crosses HBM once.
+//
+// shuffle_residual: replaces  permute(0,2,3,1).contiguous() + cat + channel_shuffle(groups=2) + residual add
+//   (MedMamba.py:354-357; channel_shuffle :308-320):
+//     out[b,p,2i]   = left[b,i,p] + inp[b,p,2i]        left: conv-branch output, NCHW (b, C/2, P)
+//     out[b,p,2i+1] = ssm[b,p,i]  + inp[b,p,2i+1]      ssm : SS2D-branch output, NHWC (b, P, C/2)
+//   The NCHW->NHWC transpose of `left` goes through a 32x33 LDS tile; all global accesses are 128-B runs.
+//   The backward is the same permutation read the other way (d_left, d_ssm from dout; d_inp = dout).
+#include "mm_common.h"
+#include "medmamba_hip.h"
+
+namespace {
+using namespace mm;
+
+// grid: (ceil(P/32), ceil(C2/32), B); block 256 = 8 rows x 32 lanes
+__global__ __launch_bounds__(256) void shuffle_residual_fwd_kernel(const float* __restrict__ left, const float* __restrict__ ssm,
+                                                                   const float* __restrict__ inp, float* __restrict__ out,
+                                                                   int P, int C2) {
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int p0 = blockIdx.x * 32, i0 = blockIdx.y * 32, b = blockIdx.z;
+  const float* lb = left + (int64_t)b * C2 * P;
+  // load left[i0+r][p0+tx] (lanes along p)
+#pragma unroll
+  for (int r = ty; r < 32; r += 8) {
+    const int i = i0 + r, p = p0 + tx;
+    tile[r][tx] = (i < C2 && p < P) ? lb[(int64_t)i * P + p] : 0.f;
+  }
+  __syncthreads();
+  // out rows: position p0+r, channel pair i0+tx (lanes along i)
+  const int64_t ob = (int64_t)b * P * (2 * C2);
+#pragma unroll
+  for (int r = ty; r < 32; r += 8) {
+    const int p = p0 + r, i = i0 + tx;
+    if (p < P && i < C2) {
+      const float2 in2 = *reinterpret_cast<const float2*>(inp + ob + (int64_t)p * 2 * C2 + 2 * i);
+      const float s = ssm[((int64_t)b * P + p) * C2 + i];
+      *reinterpret_cast<float2*>(out + ob + (int64_t)p * 2 * C2 + 2 * i) = make_float2(tile[tx][r] + in2.x, s + in2.y);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void shuffle_residual_bwd_kernel(const float* __restrict__ dout, float* __restrict__ dleft,
+                                                                   float* __restrict__ dssm, int P, int C2) {
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int p0 = blockIdx.x * 32, i0 = blockIdx.y * 32, b = blockIdx.z;
+  const int64_t ob = (int64_t)b * P * (2 * C2);
+#pragma unroll
+  for (int r = ty; r < 32; r += 8) {
+    const int p = p0 + r, i = i0 + tx;
+    float2 g = make_float2(0.f, 0.f);
+    if (p < P && i < C2) {
+      g = *reinterpret_cast<const float2*>(dout + ob + (int64_t)p * 2 * C2 + 2 * i);
+      dssm[((int64_t)b * P + p) * C2 + i] = g.y;
+    }
+    tile[r][tx] = g.x;       // [p][i]
+  }
+  __syncthreads();
+  float* lb = dleft + (int64_t)b * C2 * P;
+#pragma unroll
+  for (int r = ty; r < 32; r += 8) {
+    const int i = i0 + r, p = p0 + tx;
+    if (i < C2 && p < P) lb[(int64_t)i * P + p] = tile[tx][r];
+  }
+}
+}  // namespace
+
+extern "C" {
+
+int mm_shuffle_residual_fwd(const float* left, const float* ssm, const float* inp, float* out, int batch, int P, int C2,
+                            void* stream) {
+  if (!left || !ssm || !inp || !out) return MM_ERR_NULL;
+  if (batch <= 0 || P <= 0 || C2 <= 0 || batch > 65535) return MM_ERR_SHAPE;
+  if ((reinterpret_cast<uintptr_t>(inp) | reinterpret_cast<uintptr_t>(out)) & 7) return MM_ERR_ALIGN;
+  dim3 grid((P + 31) / 32, (C2 + 31) / 32, batch);
+  hipLaunchKernelGGL(shuffle_residual_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, left, ssm, inp, out, P, C2);
+  return (int)hipGetLastError();
+}
+
+int mm_shuffle_residual_bwd(const float* dout, float* dleft, float* dssm, int batch, int P, int C2, void* stream) {
+  if (!dout || !dleft || !dssm) return MM_ERR_NULL;
+  if (batch <= 0 || P <= 0 || C2 <= 0 || batch > 65535) return MM_ERR_SHAPE;
+  if (reinterpret_cast<uintptr_t>(dout) & 7) return MM_ERR_ALIGN;
+  dim3 grid((P + 31) / 32, (C2 + 31) / 32, batch);
+  hipLaunchKernelGGL(shuffle_residual_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, dout, dleft, dssm, P, C2);
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"
+
+// =====================================================================================================
+// SS2D in channel-first planes.  Between in_proj and out_proj every tensor lives as (batch, channel, H*W)
+// planes, so the reference's NHWC<->NCHW permute copies (MedMamba.py:294, 299) and the transposes of the
+// cross-scan / cross-merge (:256, :283-284) become per-plane operations with 128-B runs on both sides.
+// =====================================================================================================
+namespace {
+
+// ---- depthwise 3x3 conv + bias + SiLU (MedMamba.py:153-162, 295), writing the scan's two input orders --------
+// x: planes (b, d) of H*W floats, batch stride x_sb, channel stride H*W.  out u2: (batch, 2, D, L):
+// u2[b,0,d,h*W+w] = u2[b,1,d,w*H+h] = silu(conv(x)[b,d,h,w] + bias[d]).  One workgroup per plane; the plane sits
+// in LDS with a zero halo; the transposed copy goes through a second LDS plane.
+__global__ __launch_bounds__(256) void dwconv_silu_cross_fwd_kernel(const float* __restrict__ x, int64_t x_sb,
+                                                                    const float* __restrict__ wgt,
+                                                                    const float* __restrict__ bias, float* __restrict__ u2,
+                                                                    int D, int H, int W) {
+  extern __shared__ float lds[];
+  const int b = blockIdx.x / D, d = blockIdx.x % D;
+  const int L = H * W, WP = W + 2, tid = threadIdx.x, nt = blockDim.x;
+  float* sx = lds;                         // (H+2) x (W+2), zero halo
+  float* so = lds + (H + 2) * WP;          // H x (W+1)
+  const float* xp = x + (int64_t)b * x_sb + (int64_t)d * L;
+  for (int i = tid; i < (H + 2) * WP; i += nt) {
+    const int hh = i / WP - 1, ww = i % WP - 1;
+    sx[i] = (hh >= 0 && hh < H && ww >= 0 && ww < W) ? xp[hh * W + ww] : 0.f;
+  }
+  float k[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) k[i] = wgt[d * 9 + i];
+  const float bs = bias ? bias[d] : 0.f;
+  __syncthreads();
+  float* o0 = u2 + ((int64_t)b * 2 * D + d) * L;
+  float* o1 = u2 + ((int64_t)b * 2 * D + D + d) * L;
+  for (int i = tid; i < L; i += nt) {
+    const int h = i / W, w = i % W;
+    const float* c = sx + h * WP + w;      // top-left of the 3x3 window
+    float p = bs;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) p = fmaf(c[kh * WP + kw], k[kh * 3 + kw], p);
+    const float v = p * sigmoid_f(p);
+    o0[i] = v;
+    so[h * (W + 1) + w] = v;
+  }
+  __syncthreads();
+  for (int i = tid; i < L; i += nt) {      // i = w*H + h  (lanes along h)
+    const int w = i / H, h = i % H;
+    o1[i] = so[h * (W + 1) + w];
+  }
+}
+
+// backward of the above: g = du2[b,0] + T(du2[b,1]);  dp = g * silu'(p);  dx = corr(dp, flipped k);
+// per-plane partial weight/bias gradients to ws[(b*D+d)*10 + 0..8 | 9].
+__global__ __launch_bounds__(256) void dwconv_silu_cross_bwd_kernel(const float* __restrict__ du2, const float* __restrict__ x,
+                                                                    int64_t x_sb, const float* __restrict__ wgt,
+                                                                    const float* __restrict__ bias, float* __restrict__ dx,
+                                                                    int64_t dx_sb, float* __restrict__ ws, int D, int H, int W) {
+  extern __shared__ float lds[];
+  const int b = blockIdx.x / D, d = blockIdx.x % D;
+  const int L = H * W, WP = W + 2, tid = threadIdx.x, nt = blockDim.x;
+  float* sx = lds;                          // (H+2) x (W+2) input, zero halo
+  float* sd = lds + (H + 2) * WP;           // (H+2) x (W+2) dp, zero halo
+  float* st = sd + (H + 2) * WP;            // H x (W+1): transposed gradient staging
+  __shared__ float red[10][4];
+  const float* xp = x + (int64_t)b * x_sb + (int64_t)d * L;
+  const float* g0 = du2 + ((int64_t)b * 2 * D + d) * L;
+  const float* g1 = du2 + ((int64_t)b * 2 * D + D + d) * L;
+  for (int i = tid; i < (H + 2) * WP; i += nt) {
+    const int hh = i / WP - 1, ww = i % WP - 1;
+    sx[i] = (hh >= 0 && hh < H && ww >= 0 && ww < W) ? xp[hh * W + ww] : 0.f;
+    sd[i] = 0.f;
+  }
+  for (int i = tid; i < L; i += nt) {       // i = w*H + h
+    const int w = i / H, h = i % H;
+    st[h * (W + 1) + w] = g1[i];
+  }
+  float k[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) k[i] = wgt[d * 9 + i];
+  const float bs = bias ? bias[d] : 0.f;
+  __syncthreads();
+  float acc[10];
+#pragma unroll
+  for (int i = 0; i < 10; ++i) acc[i] = 0.f;
+  for (int i = tid; i < L; i += nt) {
+    const int h = i / W, w = i % W;
+    const float* c = sx + h * WP + w;
+    float p = bs;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) p = fmaf(c[kh * WP + kw], k[kh * 3 + kw], p);
+    const float s = sigmoid_f(p);
+    const float dp = (g0[i] + st[h * (W + 1) + w]) * (s * (1.f + p * (1.f - s)));   // silu'(p) = s (1 + p (1 - s))
+    sd[(h + 1) * WP + (w + 1)] = dp;
+    acc[9] += dp;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) acc[kh * 3 + kw] = fmaf(dp, c[kh * WP + kw], acc[kh * 3 + kw]);
+  }
+  __syncthreads();
+  float* dxp = dx + (int64_t)b * dx_sb + (int64_t)d * L;
+  for (int i = tid; i < L; i += nt) {
+    const int h = i / W, w = i % W;
+    // dx[h,w] = sum_{kh,kw} dp[h-kh+1, w-kw+1] * k[kh][kw]   (sd is offset by +1 in both dims)
+    float v = 0.f;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) v = fmaf(sd[(h - kh + 2) * WP + (w - kw + 2)], k[kh * 3 + kw], v);
+    dxp[i] = v;
+  }
+  // plane reduction of the 10 partial sums: wave (DPP + shuffles), then across waves through LDS
+  const int lane = tid & 63, wv = tid >> 6, nw = (nt + 63) >> 6;
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    float v = group_sum<16>(acc[i]);
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    if (lane == 0) red[i][wv] = v;
+  }
+  __syncthreads();
+  if (tid < 10) {
+    float v = 0.f;
+    for (int j = 0; j < nw; ++j) v += red[tid][j];
+    ws[(int64_t)blockIdx.x * 10 + tid] = v;
+  }
+}
+
+// ---- cross-merge (MedMamba.py:282-286, 298): m[b,d,h*W+w] = o[b,0,d,hw] + o[b,1,d,hw] + o[b,2,d,wh] + o[b,3,d,wh] ----
+// o: (batch, 4, D, L) in position order (directions: row-major fwd/rev, column-major fwd/rev).  32x32 tiles per plane.
+// grid: ceil(W/32) * ceil(H/32) * batch*D blocks (flattened)
+__global__ __launch_bounds__(256) void cross_merge_fwd_kernel(const float* __restrict__ o, float* __restrict__ m, int D, int H, int W) {
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int nbw = (W + 31) / 32, nbh = (H + 31) / 32;
+  const int w0 = (blockIdx.x % nbw) * 32, h0 = ((blockIdx.x / nbw) % nbh) * 32, pl = blockIdx.x / (nbw * nbh);
+  const int b = pl / D, d = pl % D;
+  const int64_t L = (int64_t)H * W;
+  const float* o0 = o + (((int64_t)b * 4 + 0) * D + d) * L;
+  const float* o1 = o0 + (int64_t)D * L;
+  const float* o2 = o1 + (int64_t)D * L;
+  const float* o3 = o2 + (int64_t)D * L;
+#pragma unroll
+  for (int r = ty; r < 32; r += 8) {         // rows w0+r of the column-major planes, lanes along h
+    const int w = w0 + r, h = h0 + tx;
+    tile[r][tx] = (w < W && h < H) ? o2[(int64_t)w * H + h] + o3[(int64_t)w * H + h] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = ty; r < 32; r += 8) {         // rows h0+r of the row-major planes, lanes along w
+    const int h = h0 + r, w = w0 + tx;
+    if (h < H && w < W) {
+      const int64_t i = (int64_t)h * W + w;
+      m[((int64_t)b * D + d) * L + i] = o0[i] + o1[i] + tile[tx][r];
+    }
+  }
+}
+
+// plane transpose: dst[pl, w*H+h] = src[pl, h*W+w]; plane pl of batch b / channel d at b*sb + d*L.
+__global__ __launch_bounds__(256) void plane_transpose_kernel(const float* __restrict__ src, int64_t src_sb,
+                                                              float* __restrict__ dst, int64_t dst_sb, int D, int H, int W) {
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int nbw = (W + 31) / 32, nbh = (H + 31) / 32;
+  const int w0 = (blockIdx.x % nbw) * 32, h0 = ((blockIdx.x / nbw) % nbh) * 32, pl = blockIdx.x / (nbw * nbh);
+  const int b = pl / D, d = pl % D;
+  const int64_t L = (int64_t)H * W;
+  const float* s = src + (int64_t)b * src_sb + (int64_t)d * L;
+  float* t = dst + (int64_t)b * dst_sb + (int64_t)d * L;
+#pragma unroll
+  for (int r = ty; r < 32; r += 8) {
+    const int h = h0 + r, w = w0 + tx;
+    tile[r][tx] = (h < H && w < W) ? s[(int64_t)h * W + w] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = ty; r < 32; r += 8) {
+    const int w = w0 + r, h = h0 + tx;
+    if (w < W && h < H) t[(int64_t)w * H + h] = tile[tx][r];
+  }
+}
+
+// ---- LayerNorm over channels (out_norm, MedMamba.py:300) + gate y*silu(z) (:301), channel-first ----------------
+// m, y: (batch, D, L) contiguous; z: planes with batch stride z_sb.  Thread layout: PW consecutive positions x TPP
+// channel chunks per wave (TPP = 64/PW lanes share a position and split D); statistics mu/rstd: (batch, L).
+template <int PW>
+__device__ __forceinline__ float pos_sum(float v) {   // sum over the 64/PW lanes that share a position
+#pragma unroll
+  for (int s = PW; s < 64; s <<= 1) v += __shfl_xor(v, s);
+  return v;
+}
+
+template <int PW>
+__global__ __launch_bounds__(256) void ln_gate_fwd_kernel(const float* __restrict__ m, const float* __restrict__ z, int64_t z_sb,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float eps, float* __restrict__ y, float* __restrict__ mu_out,
+                                                          float* __restrict__ rstd_out, int D, int L, int npos_blocks) {
+  constexpr int TPP = 64 / PW;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int b = blockIdx.x / npos_blocks, pb = blockIdx.x % npos_blocks;
+  const int p = (pb * 4 + wv) * PW + (lane % PW);
+  const int ck = lane / PW;                               // channel chunk of this lane
+  const bool ok = p < L;
+  const float* mp = m + (int64_t)b * D * L + p;
+  const float* zp = z + (int64_t)b * z_sb + p;
+  const float shift = ok ? mp[0] : 0.f;                   // shifted one-pass variance (shift = channel 0)
+  float s1 = 0.f, s2 = 0.f;
+  for (int d = ck; d < D; d += TPP) {
+    const float v = ok ? mp[(int64_t)d * L] - shift : 0.f;
+    s1 += v;
+    s2 = fmaf(v, v, s2);
+  }
+  s1 = pos_sum<PW>(s1);
+  s2 = pos_sum<PW>(s2);
+  const float mean_s = s1 / D;
+  const float var = fmaxf(s2 / D - mean_s * mean_s, 0.f);
+  const float mu = mean_s + shift, rstd = __builtin_amdgcn_rsqf(var + eps);
+  if (ok && ck == 0) {
+    mu_out[(int64_t)b * L + p] = mu;
+    rstd_out[(int64_t)b * L + p] = rstd;
+  }
+  if (!ok) return;
+  float* yp = y + (int64_t)b * D * L + p;
+  for (int d = ck; d < D; d += TPP) {
+    const float n = (mp[(int64_t)d * L] - mu) * rstd * gamma[d] + beta[d];
+    const float zz = zp[(int64_t)d * L];
+    yp[(int64_t)d * L] = n * (zz * sigmoid_f(zz));
+  }
+}
+
+// backward: dm (written with batch stride dm_sb), dz (batch stride dz_sb), and per-wave partial sums of
+// dgamma / dbeta to ws[(wave_global) * 2 * D + {0: dgamma, D: dbeta} + d]  (summed by the caller).
+template <int PW>
+__global__ __launch_bounds__(256) void ln_gate_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ m,
+                                                          const float* __restrict__ z, int64_t z_sb,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          const float* __restrict__ mu_in, const float* __restrict__ rstd_in,
+                                                          float* __restrict__ dm, int64_t dm_sb, float* __restrict__ dz,
+                                                          int64_t dz_sb, float* __restrict__ ws, int D, int L, int npos_blocks) {
+  constexpr int TPP = 64 / PW;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int b = blockIdx.x / npos_blocks, pb = blockIdx.x % npos_blocks;
+  const int p = (pb * 4 + wv) * PW + (lane % PW);
+  const int ck = lane / PW;
+  const bool ok = p < L;
+  const float* mp = m + (int64_t)b * D * L + p;
+  const float* gp = dy + (int64_t)b * D * L + p;
+  const float* zp = z + (int64_t)b * z_sb + p;
+  const float mu = ok ? mu_in[(int64_t)b * L + p] : 0.f, rstd = ok ? rstd_in[(int64_t)b * L + p] : 0.f;
+  float c1 = 0.f, c2 = 0.f;
+  for (int d = ck; d < D; d += TPP) {
+    if (ok) {
+      const float zz = zp[(int64_t)d * L];
+      const float dn = gp[(int64_t)d * L] * (zz * sigmoid_f(zz)) * gamma[d];
+      const float xh = (mp[(int64_t)d * L] - mu) * rstd;
+      c1 += dn;
+      c2 = fmaf(dn, xh, c2);
+    }
+  }
+  c1 = pos_sum<PW>(c1) / D;
+  c2 = pos_sum<PW>(c2) / D;
+  float* dmp = dm + (int64_t)b * dm_sb + p;
+  float* dzp = dz + (int64_t)b * dz_sb + p;
+  float* wrow = ws + ((int64_t)blockIdx.x * 4 + wv) * 2 * D;
+  for (int d0 = 0; d0 < D; d0 += TPP) {
+    const int d = d0 + ck;
+    float pg = 0.f, pb_ = 0.f;
+    if (ok && d < D) {
+      const float zz = zp[(int64_t)d * L], s = sigmoid_f(zz), sz = zz * s;
+      const float g = gp[(int64_t)d * L];
+      const float xh = (mp[(int64_t)d * L] - mu) * rstd;
+      const float n = xh * gamma[d] + beta[d];
+      const float dn = g * sz;
+      dzp[(int64_t)d * L] = g * n * (s * (1.f + zz * (1.f - s)));
+      dmp[(int64_t)d * L] = rstd * (dn * gamma[d] - c1 - xh * c2);
+      pg = dn * xh;
+      pb_ = dn;
+    }
+    // sum over the PW positions of this wave that share channel d (lanes with equal ck): xor over the low bits
+#pragma unroll
+    for (int s = 1; s < PW; s <<= 1) {
+      pg += __shfl_xor(pg, s);
+      pb_ += __shfl_xor(pb_, s);
+    }
+    if ((lane % PW) == 0 && d < D) {
+      wrow[d] = pg;
+      wrow[D + d] = pb_;
+    }
+  }
+}
+
+inline int pick_pw(int batch, int L) {   // positions per wave: fewer when there are few positions (small images)
+  const long npos = (long)batch * L;
+  if (npos >= 64 * 1024) return 64;
+  if (npos >= 16 * 1024) return 16;
+  return 4;
+}
+}  // namespace
+
+extern "C" {
+
+int mm_dwconv_silu_cross_fwd(const float* x, int64_t x_sb, const float* w, const float* bias, float* u2, int batch, int D,
+                             int H, int W, void* stream) {
+  if (!x || !w || !u2) return MM_ERR_NULL;
+  if (batch <= 0 || D <= 0 || H <= 0 || W <= 0) return MM_ERR_SHAPE;
+  const size_t lds = sizeof(float) * ((size_t)(H + 2) * (W + 2) + (size_t)H * (W + 1));
+  if (lds > 150 * 1024) return MM_ERR_UNSUPPORTED;
+  const int L = H * W, nt = L >= 1024 ? 256 : (L > 64 ? 128 : 64);
+  if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)dwconv_silu_cross_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(dwconv_silu_cross_fwd_kernel, dim3(batch * D), dim3(nt), lds, (hipStream_t)stream, x, x_sb, w, bias, u2, D, H, W);
+  return (int)hipGetLastError();
+}
+
+int mm_dwconv_silu_cross_bwd(const float* du2, const float* x, int64_t x_sb, const float* w, const float* bias, float* dx,
+                             int64_t dx_sb, float* ws, int batch, int D, int H, int W, void* stream) {
+  if (!du2 || !x || !w || !dx || !ws) return MM_ERR_NULL;
+  if (batch <= 0 || D <= 0 || H <= 0 || W <= 0) return MM_ERR_SHAPE;
+  const size_t lds = sizeof(float) * (2 * (size_t)(H + 2) * (W + 2) + (size_t)H * (W + 1));
+  if (lds > 150 * 1024) return MM_ERR_UNSUPPORTED;
+  const int L = H * W, nt = L >= 1024 ? 256 : (L > 64 ? 128 : 64);
+  if (lds > 60 * 1024) (void)hipFuncSetAttribute((const void*)dwconv_silu_cross_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(dwconv_silu_cross_bwd_kernel, dim3(batch * D), dim3(nt), lds, (hipStream_t)stream, du2, x, x_sb, w, bias,
+                     dx, dx_sb, ws, D, H, W);
+  return (int)hipGetLastError();
+}
+
+int mm_cross_merge_fwd(const float* out4, float* m, int batch, int D, int H, int W, void* stream) {
+  if (!out4 || !m) return MM_ERR_NULL;
+  if (batch <= 0 || D <= 0 || H <= 0 || W <= 0) return MM_ERR_SHAPE;
+  hipLaunchKernelGGL(cross_merge_fwd_kernel, dim3(((W + 31) / 32) * ((H + 31) / 32) * batch * D), dim3(256), 0, (hipStream_t)stream,
+                     out4, m, D, H, W);
+  return (int)hipGetLastError();
+}
+
+int mm_plane_transpose(const float* src, int64_t src_sb, float* dst, int64_t dst_sb, int batch, int D, int H, int W, void* stream) {
+  if (!src || !dst) return MM_ERR_NULL;
+  if (batch <= 0 || D <= 0 || H <= 0 || W <= 0) return MM_ERR_SHAPE;
+  hipLaunchKernelGGL(plane_transpose_kernel, dim3(((W + 31) / 32) * ((H + 31) / 32) * batch * D), dim3(256), 0, (hipStream_t)stream,
+                     src, src_sb, dst, dst_sb, D, H, W);
+  return (int)hipGetLastError();
+}
+
+int mm_ln_gate_rows(int batch, int L) {   // rows of the dgamma/dbeta workspace written by mm_ln_gate_bwd
+  const int pw = pick_pw(batch, L);
+  return batch * ((L + 4 * pw - 1) / (4 * pw)) * 4;
+}
+
+int mm_ln_gate_fwd(const float* m, const float* z, int64_t z_sb, const float* gamma, const float* beta, float eps, float* y,
+                   float* mu, float* rstd, int batch, int D, int L, void* stream) {
+  if (!m || !z || !gamma || !beta || !y || !mu || !rstd) return MM_ERR_NULL;
+  if (batch <= 0 || D <= 0 || L <= 0) return MM_ERR_SHAPE;
+  const int pw = pick_pw(batch, L), npb = (L + 4 * pw - 1) / (4 * pw);
+  const dim3 grid(batch * npb), blk(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (pw == 64) hipLaunchKernelGGL(ln_gate_fwd_kernel<64>, grid, blk, 0, s, m, z, z_sb, gamma, beta, eps, y, mu, rstd, D, L, npb);
+  else if (pw == 16) hipLaunchKernelGGL(ln_gate_fwd_kernel<16>, grid, blk, 0, s, m, z, z_sb, gamma, beta, eps, y, mu, rstd, D, L, npb);
+  else hipLaunchKernelGGL(ln_gate_fwd_kernel<4>, grid, blk, 0, s, m, z, z_sb, gamma, beta, eps, y, mu, rstd, D, L, npb);
+  return (int)hipGetLastError();
+}
+
+int mm_ln_gate_bwd(const float* dy, const float* m, const float* z, int64_t z_sb, const float* gamma, const float* beta,
+                   const float* mu, const float* rstd, float* dm, int64_t dm_sb, float* dz, int64_t dz_sb, float* ws, int batch,
+                   int D, int L, void* stream) {
+  if (!dy || !m || !z || !gamma || !beta || !mu || !rstd || !dm || !dz || !ws) return MM_ERR_NULL;
+  if (batch <= 0 || D <= 0 || L <= 0) return MM_ERR_SHAPE;
+  const int pw = pick_pw(batch, L), npb = (L + 4 * pw - 1) / (4 * pw);
+  const dim3 grid(batch * npb), blk(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (pw == 64) hipLaunchKernelGGL(ln_gate_bwd_kernel<64>, grid, blk, 0, s, dy, m, z, z_sb, gamma, beta, mu, rstd, dm, dm_sb, dz, dz_sb, ws, D, L, npb);
+  else if (pw == 16) hipLaunchKernelGGL(ln_gate_bwd_kernel<16>, grid, blk, 0, s, dy, m, z, z_sb, gamma, beta, mu, rstd, dm, dm_sb, dz, dz_sb, ws, D, L, npb);
+  else hipLaunchKernelGGL(ln_gate_bwd_kernel<4>, grid, blk, 0, s, dy, m, z, z_sb, gamma, beta, mu, rstd, dm, dm_sb, dz, dz_sb, ws, D, L, npb);
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"

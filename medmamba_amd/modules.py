@@ -24,6 +24,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 import torch.utils.checkpoint as checkpoint
 
+from .ops import dwconv_silu_cross, shuffle_residual, ss2d_core
 from .selective_scan_interface import CROSS_SCAN_K_OF_G, cross_scan_fn, selective_scan_fn
 
 trunc_normal_ = nn.init.trunc_normal_   # timm.layers.trunc_normal_ == torch.nn.init.trunc_normal_
@@ -212,10 +213,32 @@ class SS2D(nn.Module):
         return y.contiguous()
 
     def forward(self, x, **kwargs):
-        x, z = self.in_proj(x).chunk(2, dim=-1)
-        x = self.act(self.conv2d(x.permute(0, 3, 1, 2).contiguous()))
-        y = self.forward_core_fused(x)
-        out = self.out_proj(self.out_norm(y) * F.silu(z))
+        """(B, H, W, d_model) -> (B, H, W, d_model).  MI355X layout: everything between in_proj and out_proj lives
+        in channel-first planes (B, channel, H*W): in_proj / out_proj are GEMMs with a transposed operand (no
+        copy), the depthwise conv, the scan, the cross-merge, out_norm and the gate are plane-wise HIP kernels, so
+        none of the reference's permute / stack / flip / transpose copies (MedMamba.py:294-299) exists."""
+        B, H, W, _ = x.shape
+        L, D, R, N = H * W, self.d_inner, self.dt_rank, self.d_state
+        Xt = x.reshape(B, L, -1).transpose(1, 2)                                           # (B, d_model, L) view
+        Wi = self.in_proj.weight                                                             # (2D, d_model)
+        x_cf, z_cf = torch.matmul(Wi[:D], Xt), torch.matmul(Wi[D:], Xt)                      # :291-292, (B, D, L) each
+        if self.in_proj.bias is not None:
+            x_cf = x_cf + self.in_proj.bias[:D, None]
+            z_cf = z_cf + self.in_proj.bias[D:, None]
+        u2 = dwconv_silu_cross(x_cf, self.conv2d.weight, self.conv2d.bias, H, W)            # :294-295 + :256
+        perm = list(CROSS_SCAN_K_OF_G)                       # kernel direction g -> reference direction k
+        Wx = self.x_proj_weight[perm].reshape(1, 2, 2 * (R + 2 * N), D)
+        x_dbl = torch.matmul(Wx, u2.view(B, 2, D, L)).view(B, 4, R + 2 * N, L)               # :259
+        dts = torch.matmul(self.dt_projs_weight[perm].unsqueeze(0), x_dbl[:, :, :R])         # :262
+        y_cf = ss2d_core(u2, dts.view(B, 4 * D, L),
+                         -torch.exp(self.A_logs.float().view(4, D, N)[perm]).view(4 * D, N),
+                         x_dbl[:, :, R:R + N], x_dbl[:, :, R + N:],
+                         self.Ds.float().view(4, D)[perm].reshape(-1), self.dt_projs_bias.float()[perm].reshape(-1),
+                         z_cf, self.out_norm.weight, self.out_norm.bias, H, W, self.out_norm.eps)   # :273-301
+        out = torch.matmul(y_cf.transpose(1, 2), self.out_proj.weight.t())                   # :302
+        if self.out_proj.bias is not None:
+            out = out + self.out_proj.bias
+        out = out.view(B, H, W, -1)
         return out if self.dropout is None else self.dropout(out)
 
 
@@ -246,8 +269,9 @@ class SS_Conv_SSM(nn.Module):
     def forward(self, input):
         left, right = input.chunk(2, dim=-1)
         x = self.drop_path(self.self_attention(self.ln_1(right)))
-        left = self.conv33conv33conv11(left.permute(0, 3, 1, 2).contiguous()).permute(0, 2, 3, 1).contiguous()
-        return channel_shuffle(torch.cat((left, x), dim=-1), groups=2) + input
+        left = self.conv33conv33conv11(left.permute(0, 3, 1, 2).contiguous())            # stays NCHW
+        # permute back + cat + channel_shuffle(groups=2) + residual (MedMamba.py:354-357) fused in one HIP kernel
+        return shuffle_residual(left, x, input)
 
 
 class VSSLayer(nn.Module):

@@ -1,0 +1,165 @@
+"""Autograd wrappers of the glue kernels in libmedmamba_hip.so (csrc/glue.hip) — HIP tensors only."""
+import torch
+
+from . import _lib
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need_hip(*ts):
+    for t in ts:
+        if not t.is_cuda:
+            raise RuntimeError("medmamba_amd.ops: tensors must live on a HIP device (there is no CPU path)")
+
+
+class ShuffleResidualFn(torch.autograd.Function):
+    """out = channel_shuffle(cat(left_nhwc, ssm), 2) + inp   (MedMamba.py:354-357) in one kernel.
+    left: (B, C/2, H, W) NCHW conv-branch output; ssm: (B, H, W, C/2); inp: (B, H, W, C)."""
+
+    @staticmethod
+    def forward(ctx, left, ssm, inp):
+        left, ssm, inp = left.float().contiguous(), ssm.float().contiguous(), inp.float().contiguous()
+        B, C2, H, W = left.shape
+        out = torch.empty_like(inp)
+        with torch.cuda.device(inp.device):
+            rc = _lib.lib().mm_shuffle_residual_fwd(left.data_ptr(), ssm.data_ptr(), inp.data_ptr(), out.data_ptr(),
+                                                    B, H * W, C2, _stream())
+        _lib.check(rc, "mm_shuffle_residual_fwd")
+        ctx.shape = (B, C2, H, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, C2, H, W = ctx.shape
+        dout = dout.float().contiguous()
+        dleft = torch.empty((B, C2, H, W), device=dout.device, dtype=torch.float32)
+        dssm = torch.empty((B, H, W, C2), device=dout.device, dtype=torch.float32)
+        with torch.cuda.device(dout.device):
+            rc = _lib.lib().mm_shuffle_residual_bwd(dout.data_ptr(), dleft.data_ptr(), dssm.data_ptr(), B, H * W, C2,
+                                                    _stream())
+        _lib.check(rc, "mm_shuffle_residual_bwd")
+        return dleft, dssm, dout
+
+
+def shuffle_residual(left_nchw, ssm_nhwc, inp_nhwc):
+    _need_hip(left_nchw, ssm_nhwc, inp_nhwc)
+    return ShuffleResidualFn.apply(left_nchw, ssm_nhwc, inp_nhwc)
+
+
+class DwConvSiluCrossFn(torch.autograd.Function):
+    """Depthwise conv3x3 + bias + SiLU on channel-first planes, written in the scan's two image orders
+    (MedMamba.py:153-162, 295 + the stack/transpose of :256).  x_cf: (B, D, L) planes (any batch stride),
+    weight (D,1,3,3), bias (D) or None  ->  u2 (B, 2*D, L)."""
+
+    @staticmethod
+    def forward(ctx, x_cf, weight, bias, H, W):
+        B, D, L = x_cf.shape
+        assert L == H * W
+        x_cf = x_cf.float()
+        if x_cf.stride(2) != 1 or x_cf.stride(1) != L:
+            x_cf = x_cf.contiguous()
+        weight = weight.float().contiguous()
+        bias = None if bias is None else bias.float().contiguous()
+        u2 = torch.empty((B, 2 * D, L), device=x_cf.device, dtype=torch.float32)
+        with torch.cuda.device(x_cf.device):
+            rc = _lib.lib().mm_dwconv_silu_cross_fwd(x_cf.data_ptr(), x_cf.stride(0), weight.data_ptr(),
+                                                     None if bias is None else bias.data_ptr(), u2.data_ptr(),
+                                                     B, D, H, W, _stream())
+        _lib.check(rc, "mm_dwconv_silu_cross_fwd")
+        ctx.save_for_backward(x_cf, weight, bias)
+        ctx.hw = (H, W)
+        return u2
+
+    @staticmethod
+    def backward(ctx, du2):
+        x_cf, weight, bias = ctx.saved_tensors
+        H, W = ctx.hw
+        B, D, L = x_cf.shape
+        du2 = du2.float().contiguous()
+        dx = torch.empty((B, D, L), device=du2.device, dtype=torch.float32)
+        ws = torch.empty((B, D, 10), device=du2.device, dtype=torch.float32)
+        with torch.cuda.device(du2.device):
+            rc = _lib.lib().mm_dwconv_silu_cross_bwd(du2.data_ptr(), x_cf.data_ptr(), x_cf.stride(0), weight.data_ptr(),
+                                                     None if bias is None else bias.data_ptr(), dx.data_ptr(), dx.stride(0),
+                                                     ws.data_ptr(), B, D, H, W, _stream())
+        _lib.check(rc, "mm_dwconv_silu_cross_bwd")
+        s = ws.sum(0)
+        return dx, s[:, :9].reshape(D, 1, 3, 3), (None if bias is None else s[:, 9].contiguous()), None, None
+
+
+def dwconv_silu_cross(x_cf, weight, bias, H, W):
+    _need_hip(x_cf, weight)
+    return DwConvSiluCrossFn.apply(x_cf, weight, bias, H, W)
+
+
+class SS2DCoreFn(torch.autograd.Function):
+    """4-direction selective scan + cross-merge + out_norm LayerNorm + SiLU(z) gate in channel-first planes
+    (MedMamba.py:273-286, 298-301).  Inputs as cross_scan_fn plus z_cf (B, D, L), LayerNorm weight/bias/eps and the
+    image size; returns y_cf (B, D, L) = LN_D(merge(scan(...))) * silu(z).
+    Saved for backward: the scan operands + checkpoints, the merged pre-norm tensor m (B,D,L) and the LN statistics;
+    the (B,4D,L) scan output is freed after the merge."""
+
+    @staticmethod
+    def forward(ctx, u2, delta, A, Bm, Cm, Dp, dbias, z_cf, ln_w, ln_b, H, W, eps):
+        from .selective_scan_interface import _CROSS_SHARED, _launch_fwd, _prep
+        u2, delta, A, Bm, Cm, Dp, dbias = _prep(u2, delta, A, Bm, Cm, Dp, dbias)
+        Bsz, D4, L = delta.shape
+        D = D4 // 4
+        need_grad = any(ctx.needs_input_grad)
+        out4, x_chk = _launch_fwd(u2, delta, A, Bm, Cm, Dp, dbias, True, need_grad, 0, _CROSS_SHARED)
+        z_cf = z_cf.float()
+        if z_cf.stride(2) != 1 or z_cf.stride(1) != L:
+            z_cf = z_cf.contiguous()
+        ln_w, ln_b = ln_w.float().contiguous(), ln_b.float().contiguous()
+        dev = u2.device
+        m = torch.empty((Bsz, D, L), device=dev, dtype=torch.float32)
+        y = torch.empty((Bsz, D, L), device=dev, dtype=torch.float32)
+        mu = torch.empty((Bsz, L), device=dev, dtype=torch.float32)
+        rstd = torch.empty((Bsz, L), device=dev, dtype=torch.float32)
+        lib = _lib.lib()
+        with torch.cuda.device(dev):
+            rc = lib.mm_cross_merge_fwd(out4.data_ptr(), m.data_ptr(), Bsz, D, H, W, _stream())
+            _lib.check(rc, "mm_cross_merge_fwd")
+            rc = lib.mm_ln_gate_fwd(m.data_ptr(), z_cf.data_ptr(), z_cf.stride(0), ln_w.data_ptr(), ln_b.data_ptr(), float(eps),
+                                    y.data_ptr(), mu.data_ptr(), rstd.data_ptr(), Bsz, D, L, _stream())
+            _lib.check(rc, "mm_ln_gate_fwd")
+        if need_grad:
+            ctx.save_for_backward(u2, delta, A, Bm, Cm, Dp, dbias, x_chk, m, mu, rstd, z_cf, ln_w, ln_b)
+            ctx.hw = (H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from .selective_scan_interface import _CROSS_SHARED, _launch_bwd
+        u2, delta, A, Bm, Cm, Dp, dbias, x_chk, m, mu, rstd, z_cf, ln_w, ln_b = ctx.saved_tensors
+        H, W = ctx.hw
+        Bsz, D, L = m.shape
+        dev = m.device
+        dy = dy.float().contiguous()
+        dout2 = torch.empty((Bsz, 2 * D, L), device=dev, dtype=torch.float32)    # block 0: dm, block 1: its plane transpose
+        dz = torch.empty((Bsz, D, L), device=dev, dtype=torch.float32)
+        lib = _lib.lib()
+        rows = lib.mm_ln_gate_rows(Bsz, L)
+        ws = torch.empty((rows, 2 * D), device=dev, dtype=torch.float32)
+        with torch.cuda.device(dev):
+            rc = lib.mm_ln_gate_bwd(dy.data_ptr(), m.data_ptr(), z_cf.data_ptr(), z_cf.stride(0), ln_w.data_ptr(), ln_b.data_ptr(),
+                                    mu.data_ptr(), rstd.data_ptr(), dout2.data_ptr(), dout2.stride(0), dz.data_ptr(),
+                                    dz.stride(0), ws.data_ptr(), Bsz, D, L, _stream())
+            _lib.check(rc, "mm_ln_gate_bwd")
+            rc = lib.mm_plane_transpose(dout2.data_ptr(), dout2.stride(0), dout2.data_ptr() + 4 * D * L, dout2.stride(0),
+                                        Bsz, D, H, W, _stream())
+            _lib.check(rc, "mm_plane_transpose")
+        wsum = ws.sum(0)
+        du4, ddelta, dA, dB, dC, dD, ddb = _launch_bwd(u2, delta, A, Bm, Cm, Dp, dbias, x_chk, dout2, True, _CROSS_SHARED)
+        d4 = du4.view(Bsz, 2, 2, D, L)
+        du2 = (d4[:, :, 0] + d4[:, :, 1]).view(Bsz, 2 * D, L)
+        return du2, ddelta, dA, dB, dC, dD, ddb, dz, wsum[:D].contiguous(), wsum[D:].contiguous(), None, None, None
+
+
+def ss2d_core(u2, delta, A, Bm, Cm, Dp, dbias, z_cf, ln_w, ln_b, H, W, eps=1e-5):
+    _need_hip(u2, delta, z_cf)
+    if A.shape[1] != 16 or Bm.shape[1] != 4 or delta.shape[1] != 2 * u2.shape[1]:
+        raise NotImplementedError("ss2d_core: expects 4 directions, d_state 16, delta with 4*D channels")
+    return SS2DCoreFn.apply(u2, delta, A, Bm, Cm, Dp, dbias, z_cf, ln_w, ln_b, H, W, eps)

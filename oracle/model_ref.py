@@ -150,3 +150,28 @@ CONFIGS = {  # train.py:179-182
 def dt_rank(dim):
     """SS2D gets d_model = dim//2 (MedMamba.py:334) and dt_rank = ceil(d_model/16) (:150)."""
     return math.ceil((dim // 2) / 16)
+
+
+def shuffle_residual_ref(left_nchw, ssm_nhwc, inp_nhwc):
+    """Test double for medmamba_amd.ops.shuffle_residual: the reference's own op chain, MedMamba.py:354-357."""
+    left = left_nchw.permute(0, 2, 3, 1).contiguous()
+    return channel_shuffle(torch.cat((left, ssm_nhwc), dim=-1), 2) + inp_nhwc
+
+
+def dwconv_silu_cross_ref(x_cf, weight, bias, H, W):
+    """Test double for medmamba_amd.ops.dwconv_silu_cross: MedMamba.py:295 on (B,D,L) planes + the two orders of :256."""
+    B, D, L = x_cf.shape
+    xc = F.silu(F.conv2d(x_cf.reshape(B, D, H, W), weight, bias, padding=1, groups=D))
+    return torch.stack([xc.reshape(B, D, L), xc.transpose(2, 3).reshape(B, D, L)], 1).reshape(B, 2 * D, L)
+
+
+def ss2d_core_ref(u2, delta, A, Bm, Cm, Dp, dbias, z_cf, ln_w, ln_b, H, W, eps=1e-5):
+    """Test double for medmamba_amd.ops.ss2d_core: oracle scan (explicit flips) + the reference's merge (:282-286, 298),
+    out_norm (:300) and gate (:301), kept channel-first."""
+    from .scan_ref import c_cross_scan_fn
+    B, D2, L = u2.shape
+    D = D2 // 2
+    y2 = c_cross_scan_fn(u2, delta, A, Bm, Cm, Dp, dbias).view(B, 2, D, L)
+    m = y2[:, 0] + y2[:, 1].reshape(B, D, W, H).transpose(2, 3).reshape(B, D, L)
+    n = F.layer_norm(m.transpose(1, 2), (D,), ln_w, ln_b, eps).transpose(1, 2)
+    return n * F.silu(z_cf)

@@ -22,6 +22,8 @@ def _build_model():
     from oracle.scan_ref import c_cross_scan_fn, c_selective_scan_fn
     M.selective_scan_fn = c_selective_scan_fn          # test doubles; the product has no CPU scan
     M.cross_scan_fn = c_cross_scan_fn
+    from oracle.model_ref import dwconv_silu_cross_ref, shuffle_residual_ref, ss2d_core_ref
+    M.shuffle_residual, M.dwconv_silu_cross, M.ss2d_core = shuffle_residual_ref, dwconv_silu_cross_ref, ss2d_core_ref
     torch.manual_seed(7)
     net = M.VSSM(num_classes=3, depths=[1, 1], dims=[16, 32], drop_path_rate=0.0)
     net.eval()       # BatchNorm uses running stats -> per-sample independence -> DDP mean == big-batch gradient
