@@ -221,7 +221,10 @@ class SS2D(nn.Module):
         L, D, R, N = H * W, self.d_inner, self.dt_rank, self.d_state
         Xt = x.reshape(B, L, -1).transpose(1, 2)                                           # (B, d_model, L) view
         Wi = self.in_proj.weight                                                             # (2D, d_model)
-        x_cf, z_cf = torch.matmul(Wi[:D], Xt), torch.matmul(Wi[D:], Xt)                      # :291-292, (B, D, L) each
+        # batched GEMMs with a broadcast weight: the outputs come out channel-first and contiguous (a plain
+        # matmul would fold the batch, produce NHWC and hand back a transposed view)
+        x_cf = torch.bmm(Wi[:D].unsqueeze(0).expand(B, -1, -1), Xt)                          # :291-292, (B, D, L)
+        z_cf = torch.bmm(Wi[D:].unsqueeze(0).expand(B, -1, -1), Xt)
         if self.in_proj.bias is not None:
             x_cf = x_cf + self.in_proj.bias[:D, None]
             z_cf = z_cf + self.in_proj.bias[D:, None]
@@ -235,7 +238,7 @@ class SS2D(nn.Module):
                          x_dbl[:, :, R:R + N], x_dbl[:, :, R + N:],
                          self.Ds.float().view(4, D)[perm].reshape(-1), self.dt_projs_bias.float()[perm].reshape(-1),
                          z_cf, self.out_norm.weight, self.out_norm.bias, H, W, self.out_norm.eps)   # :273-301
-        out = torch.matmul(y_cf.transpose(1, 2), self.out_proj.weight.t())                   # :302
+        out = torch.bmm(y_cf.transpose(1, 2), self.out_proj.weight.t().unsqueeze(0).expand(B, -1, -1))   # :302, (B, L, d_model)
         if self.out_proj.bias is not None:
             out = out + self.out_proj.bias
         out = out.view(B, H, W, -1)
