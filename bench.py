@@ -97,6 +97,8 @@ def main():
     ap.add_argument("--size", default="S", choices=["T", "S", "B", "Te"])
     ap.add_argument("--res", type=int, default=224)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse)")
+    ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -104,11 +106,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU path)")
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)     # "nccl" is RCCL on ROCm
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)     # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group(backend=args.backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from medmamba_amd.modules import VSSM, MEDMAMBA_CONFIGS

@@ -53,7 +53,10 @@ def _worker(rank, world, port, outdir):
     dist.destroy_process_group()
 
 
-def test_ddp_gradients_match_single_process(tmp_path):
+def test_ddp_gradients_match_single_process(tmp_path, monkeypatch):
+    from medmamba_amd import modules as M
+    for name in ("selective_scan_fn", "cross_scan_fn", "shuffle_residual", "dwconv_silu_cross", "ss2d_core"):
+        monkeypatch.setattr(M, name, getattr(M, name))      # restore the product functions after this test
     world, port = 2, _free_port()
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     r0 = torch.load(tmp_path / "r0.pt")
