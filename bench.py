@@ -164,13 +164,21 @@ def main():
     if rank == 0:
         ks = KERNEL_TIMER.summary()
 
+        try:      # PMC-derived HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/scan_traffic.json)
+            traffic = json.load(open(os.path.join(ROOT, "profiles", "scan_traffic.json")))
+        except Exception:
+            traffic = {}
+        std_workload = (args.size == "S" and args.batch == 64 and args.res == 224)
+
         def roof(tag):
             d = ks.get(tag)
             if not d or d["ms"] <= 0:
                 return None
             gbs = d["bytes"] / d["ms"] / 1e6
+            tr = traffic.get(tag, {}).get("bytes_per_launch") if std_workload else None
+            tr = None if tr is None else round(tr * d["calls"] / d["ms"] / 1e6, 1)      # GB/s, same basis as `achieved`
             return {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "kernel": tag,
+                    "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": tr, "kernel": tag,
                     "calls": d["calls"], "avg_us_per_call": round(1e3 * d["ms"] / d["calls"], 2),
                     "algorithmic_MB_per_call": round(d["bytes"] / d["calls"] / 1e6, 2)}
 
