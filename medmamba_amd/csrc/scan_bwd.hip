@@ -381,7 +381,14 @@ int scan_bwd_launch(const mm_scan_args* a, hipStream_t stream) {
   const int64_t span = (int64_t)a->dim * (a->u_sd > a->L ? a->u_sd : a->L) * 4;
   if (span >= 0x7ffffff0ll || (int64_t)kNState * a->B_sn * 4 >= 0x7ffffff0ll) return MM_ERR_UNSUPPORTED;
   const int waves_needed = (p.H + CH - 1) / CH;
-  const int ncw0 = (waves_needed + 7) / 8;                   // <= 8 waves per workgroup
+  // waves per workgroup: <= 8 (register budget); fewer when (batch, direction) pairs alone cannot fill 256 CUs
+  // with two workgroups each — the price is fp32 atomics on dB/dC from the workgroups that share a direction
+  // (measured, S/Bz=64: 4-wave workgroups are 7-15 % faster than 8-wave ones once a direction needs several anyway)
+  int maxw = (waves_needed <= 8 && (long)a->batch * a->G >= 256) ? 8 : 4;
+  const int forced = (a->variant >> 16) & 0xff;              // tuning override
+  if (forced > 0) maxw = forced > 8 ? 8 : forced;
+  else while (maxw > 2 && (long)a->batch * a->G * ((waves_needed + maxw - 1) / maxw) < 512) maxw >>= 1;
+  const int ncw0 = (waves_needed + maxw - 1) / maxw;
   const int waves = (waves_needed + ncw0 - 1) / ncw0;
   p.CW = waves * CH;
   p.ncw = (p.H + p.CW - 1) / p.CW;

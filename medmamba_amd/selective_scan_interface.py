@@ -51,6 +51,7 @@ class _KernelTimer:
 
 
 KERNEL_TIMER = _KernelTimer()
+_BWD_VARIANT = int(__import__("os").environ.get("MM_BWD_VARIANT", "0"))   # tuning knob: waves per workgroup << 16
 
 
 def scan_bytes_fwd(batch, dim, L, N, G):
@@ -147,6 +148,7 @@ def _launch_bwd(u, delta, A, B, C, D, delta_bias, x_chk, dout, delta_softplus, s
     a.du, a.ddelta, a.dA, a.dB, a.dC = du.data_ptr(), ddelta.data_ptr(), dA.data_ptr(), dB.data_ptr(), dC.data_ptr()
     a.dD, a.ddelta_bias = _ptr(dD), _ptr(dbias)
     a.u_groups, a.u_map, a.rev_mask = shared
+    a.variant = _BWD_VARIANT
     with torch.cuda.device(dev):
         t0 = KERNEL_TIMER.start()
         rc = _lib.lib().mm_scan_bwd(a, torch.cuda.current_stream().cuda_stream)

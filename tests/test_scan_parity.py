@@ -127,6 +127,13 @@ def test_forward_default_plan_real_stage_shapes():
         _check_fwd(_make(2, G, H, L, seed=L), True, 0)
 
 
+def test_long_sequence_config5_shape():
+    """BASELINE config 5 (MedMamba-B, 384^2): stage-1 sequence length L = 9216, forward and backward."""
+    args = _make(1, 4, 16, 9216, R=4, seed=11)
+    _check_fwd(args, True, 0)
+    _check_bwd(args)
+
+
 def test_forward_options():
     base = _make(2, 4, 16, 100, seed=5)
     u, delta, A, B, C, D, bias, dout = base

@@ -76,6 +76,8 @@ def main():
         med_f, _ = timeit(lambda: SelectiveScanFn.apply(*ins, True, 0))
         out = SelectiveScanFn.apply(*ins, True, 0)
         med_b, mn_b = timeit(lambda: torch.autograd.grad(out, ins, dout, retain_graph=True), iters=10)
+        if os.environ.get("MM_BWD_WAVES"):
+            pass
         row = dict(model=model, batch=Bz, D=D, L=L, blocks=nblk, variant="train", fwd_chk_ms=med_f, bwd_ms=med_b,
                    bwd_min_ms=mn_b, bwd_GBs=bb / med_b / 1e6, note="bwd_ms includes zero-fill of dA/dB/dC")
         rows.append(row)
