@@ -213,15 +213,23 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(const FwdParams p) {
       return o;
     };
     auto compute = [&](const Ops& o, int tg) {
+      // all 4*NS decay factors of the group first, then the dependent FMA chains: a v_exp_f32 result that is consumed
+      // 2-3 instructions later stalls a wave that has no partner on its SIMD (the transcendental pipe takes 8 cycles
+      // per instruction, but it runs beside the VALU) — keeping the two blocks apart removes that exposure
+      float a[4][NS];
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int j = 0; j < NS; ++j) a[e][j] = __builtin_amdgcn_exp2f(f4get(o.dl4, e) * A2[j]);
+      __builtin_amdgcn_sched_barrier(0);
       float4 y4;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float dl = f4get(o.dl4, e), du = f4get(o.du4, e);
+        const float du = f4get(o.du4, e);
         float y = 0.f;
 #pragma unroll
         for (int j = 0; j < NS; ++j) {
-          const float a = __builtin_amdgcn_exp2f(dl * A2[j]);
-          x[j] = fmaf(a, x[j], du * f4get(o.Bv[j], e));
+          x[j] = fmaf(a[e][j], x[j], du * f4get(o.Bv[j], e));
           y = fmaf(x[j], f4get(o.Cv[j], e), y);
         }
         (&y4.x)[e] = group_sum<SG>(y);
@@ -339,7 +347,9 @@ int scan_fwd_launch(const mm_scan_args* a, hipStream_t stream) {
                    a->C_sb % 4 == 0 && a->C_sg % 4 == 0 && a->C_sn % 4 == 0;
   const bool sp = a->delta_softplus != 0;
   // variant bit 24: force LEAN on, bit 25: force LEAN off; default: lean when the grid offers >= 3 waves per SIMD
-  bool lean = p.nwaves_total >= 3 * 1024;
+  // (measured, S/Bz=64: LEAN wins for NS=4 at >= 3072 waves: 0.19 vs 0.21 ms stage 2, 0.088 vs 0.105 ms stage 3;
+  //  it loses for NS=2 on the long stage-1 sequences: 0.49 vs 0.43 ms)
+  bool lean = ns == 4 && p.nwaves_total >= 3 * 1024;
   if (a->variant & (1 << 24)) lean = true;
   if (a->variant & (1 << 25)) lean = false;
   switch (ns) {
