@@ -25,6 +25,16 @@ def split_sd(fx, prefix="sd/"):
     return {k[len(prefix):]: torch.from_numpy(v.copy()) for k, v in fx.items() if k.startswith(prefix)}
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _built_library():
+    """Build libmedmamba_hip.so (hipcc cross-compiles without a GPU) and the C oracle once per session if missing."""
+    from medmamba_amd.build import SO, build
+    if not os.path.exists(SO):
+        build()
+    from oracle.scan_ref import build_c_oracle
+    build_c_oracle()
+
+
 @pytest.fixture(scope="session")
 def golden():
     return load_golden
