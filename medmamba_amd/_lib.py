@@ -48,6 +48,10 @@ SYMBOLS = {
     "mm_ln_gate_bwd": (ctypes.c_int, [_f32p, _f32p, _f32p, ctypes.c_int64, _f32p, _f32p, _f32p, _f32p, _f32p, ctypes.c_int64,
                                       _f32p, ctypes.c_int64, _f32p] + [ctypes.c_int] * 3 + [ctypes.c_void_p]),
     "mm_ln_gate_rows": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
+    "mm_block_split_fwd": (ctypes.c_int, [_f32p, _f32p, _f32p, ctypes.c_float, _f32p, _f32p, _f32p, _f32p] + [ctypes.c_int] * 3
+                           + [ctypes.c_void_p]),
+    "mm_block_split_bwd": (ctypes.c_int, [_f32p] * 8 + [ctypes.c_int] * 3 + [ctypes.c_void_p]),
+    "mm_block_split_rows": (ctypes.c_int, [ctypes.c_int] * 3),
     "mm_shuffle_residual_bwd": (ctypes.c_int, [_f32p] * 3 + [ctypes.c_int] * 3 + [ctypes.c_void_p]),
 }
 

@@ -466,3 +466,205 @@ int mm_ln_gate_bwd(const float* dy, const float* m, const float* z, int64_t z_sb
 }
 
 }  // extern "C"
+
+// =====================================================================================================
+// Block prologue of SS_Conv_SSM.forward (MedMamba.py:350-352): one pass splits the NHWC block input into
+//   left  -> NCHW (batch, C2, P) for the conv branch           (replaces chunk + permute(0,3,1,2).contiguous())
+//   right -> LayerNorm over its C2 channels, NHWC (batch, P, C2) (replaces chunk + ln_1 on a strided view)
+// and the backward writes both halves of d(input) in place (no cat).  ATen's LayerNorm runs at < 0.4 TB/s on
+// 48-channel rows; here 16 (or 64) lanes share a row, the row lives in registers, exact two-pass statistics.
+// =====================================================================================================
+namespace {
+
+template <int TPR>
+__device__ __forceinline__ float row_sum(float v) {
+  v = group_sum<16>(v);
+  if constexpr (TPR == 64) { v += __shfl_xor(v, 16); v += __shfl_xor(v, 32); }
+  return v;
+}
+
+constexpr int kLnNV = 8;   // channels per lane (C2 <= 8 * TPR)
+
+template <int TPR>
+__global__ __launch_bounds__(256) void ln_half_fwd_kernel(const float* __restrict__ inp, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float eps, float* __restrict__ rn,
+                                                          float* __restrict__ mu_out, float* __restrict__ rstd_out,
+                                                          int64_t nrows, int C, int C2) {
+  constexpr int RPW = 64 / TPR;
+  const int lane = threadIdx.x & 63, lr = lane % TPR;
+  const int64_t wave_global = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+  float gm[kLnNV], bt[kLnNV];
+#pragma unroll
+  for (int k = 0; k < kLnNV; ++k) {
+    const int c = lr + k * TPR;
+    gm[k] = c < C2 ? gamma[c] : 0.f;
+    bt[k] = c < C2 ? beta[c] : 0.f;
+  }
+  for (int64_t rg = wave_global; rg * RPW < nrows; rg += nwaves) {
+    const int64_t row = rg * RPW + lane / TPR;
+    const bool rok = row < nrows;
+    const float* xr = inp + row * C + C2;
+    float x[kLnNV], s = 0.f;
+#pragma unroll
+    for (int k = 0; k < kLnNV; ++k) {
+      const int c = lr + k * TPR;
+      x[k] = (rok && c < C2) ? xr[c] : 0.f;
+      s += x[k];
+    }
+    const float mean = row_sum<TPR>(s) / C2;
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < kLnNV; ++k) {
+      const float dlt = (lr + k * TPR < C2) ? x[k] - mean : 0.f;
+      v = fmaf(dlt, dlt, v);
+    }
+    const float rstd = __builtin_amdgcn_rsqf(row_sum<TPR>(v) / C2 + eps);
+    if (rok) {
+#pragma unroll
+      for (int k = 0; k < kLnNV; ++k) {
+        const int c = lr + k * TPR;
+        if (c < C2) rn[row * C2 + c] = (x[k] - mean) * rstd * gm[k] + bt[k];
+      }
+      if (lr == 0) { mu_out[row] = mean; rstd_out[row] = rstd; }
+    }
+  }
+}
+
+// d_inp[row, C2 + c] = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = d_rn * gamma;  per-wave partial dgamma / dbeta rows.
+template <int TPR>
+__global__ __launch_bounds__(256) void ln_half_bwd_kernel(const float* __restrict__ drn, const float* __restrict__ inp,
+                                                          const float* __restrict__ gamma, const float* __restrict__ mu_in,
+                                                          const float* __restrict__ rstd_in, float* __restrict__ dinp,
+                                                          float* __restrict__ ws, int64_t nrows, int C, int C2) {
+  constexpr int RPW = 64 / TPR;
+  const int lane = threadIdx.x & 63, lr = lane % TPR;
+  const int64_t wave_global = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+  float gm[kLnNV], ag[kLnNV], ab[kLnNV];
+#pragma unroll
+  for (int k = 0; k < kLnNV; ++k) {
+    gm[k] = (lr + k * TPR < C2) ? gamma[lr + k * TPR] : 0.f;
+    ag[k] = 0.f; ab[k] = 0.f;
+  }
+  for (int64_t rg = wave_global; rg * RPW < nrows; rg += nwaves) {
+    const int64_t row = rg * RPW + lane / TPR;
+    const bool rok = row < nrows;
+    const float mean = rok ? mu_in[row] : 0.f, rstd = rok ? rstd_in[row] : 0.f;
+    float xh[kLnNV], g[kLnNV], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < kLnNV; ++k) {
+      const int c = lr + k * TPR;
+      const bool ok = rok && c < C2;
+      const float d = ok ? drn[row * C2 + c] : 0.f;
+      xh[k] = ok ? (inp[row * C + C2 + c] - mean) * rstd : 0.f;
+      g[k] = d * gm[k];
+      s1 += g[k];
+      s2 = fmaf(g[k], xh[k], s2);
+      ag[k] = fmaf(d, xh[k], ag[k]);
+      ab[k] += d;
+    }
+    const float c1 = row_sum<TPR>(s1) / C2, c2 = row_sum<TPR>(s2) / C2;
+    if (rok) {
+#pragma unroll
+      for (int k = 0; k < kLnNV; ++k) {
+        const int c = lr + k * TPR;
+        if (c < C2) dinp[row * C + C2 + c] = rstd * (g[k] - c1 - xh[k] * c2);
+      }
+    }
+  }
+  // fold the RPW row slots of the wave (lanes with equal lr), then one partial row per wave
+  float* wrow = ws + wave_global * 2 * C2;
+#pragma unroll
+  for (int k = 0; k < kLnNV; ++k) {
+    float a = ag[k], bsum = ab[k];
+    if constexpr (TPR == 16) {
+      a += __shfl_xor(a, 16); a += __shfl_xor(a, 32);
+      bsum += __shfl_xor(bsum, 16); bsum += __shfl_xor(bsum, 32);
+    }
+    const int c = lr + k * TPR;
+    if (lane < TPR && c < C2) { wrow[c] = a; wrow[C2 + c] = bsum; }
+  }
+}
+
+// dst[b, i, p] = src[b, p, i] for i < C2 (src row stride C): NHWC half -> NCHW.  REV: the other way round
+// (dst[b, p, i] = src[b, i, p] written into a buffer with row stride C).  grid: ceil(P/32) * ceil(C2/32) * batch
+template <bool REV>
+__global__ __launch_bounds__(256) void half_transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int P, int C,
+                                                             int C2) {
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int nbp = (P + 31) / 32, nbi = (C2 + 31) / 32;
+  const int p0 = (blockIdx.x % nbp) * 32, i0 = ((blockIdx.x / nbp) % nbi) * 32, b = blockIdx.x / (nbp * nbi);
+  if constexpr (!REV) {
+    const float* s = src + (int64_t)b * P * C;
+#pragma unroll
+    for (int r = ty; r < 32; r += 8) {           // rows p, lanes along i
+      const int p = p0 + r, i = i0 + tx;
+      tile[r][tx] = (p < P && i < C2) ? s[(int64_t)p * C + i] : 0.f;
+    }
+    __syncthreads();
+    float* d = dst + (int64_t)b * C2 * P;
+#pragma unroll
+    for (int r = ty; r < 32; r += 8) {           // rows i, lanes along p
+      const int i = i0 + r, p = p0 + tx;
+      if (i < C2 && p < P) d[(int64_t)i * P + p] = tile[tx][r];
+    }
+  } else {
+    const float* s = src + (int64_t)b * C2 * P;
+#pragma unroll
+    for (int r = ty; r < 32; r += 8) {
+      const int i = i0 + r, p = p0 + tx;
+      tile[r][tx] = (i < C2 && p < P) ? s[(int64_t)i * P + p] : 0.f;
+    }
+    __syncthreads();
+    float* d = dst + (int64_t)b * P * C;
+#pragma unroll
+    for (int r = ty; r < 32; r += 8) {
+      const int p = p0 + r, i = i0 + tx;
+      if (p < P && i < C2) d[(int64_t)p * C + i] = tile[tx][r];
+    }
+  }
+}
+
+inline int ln_half_grid(int64_t nrows, int tpr) {
+  const int64_t waves = (nrows + (64 / tpr) - 1) / (64 / tpr);
+  int64_t blocks = (waves + 3) / 4;
+  if (blocks > 2048) blocks = 2048;
+  return (int)blocks;
+}
+}  // namespace
+
+extern "C" {
+
+int mm_block_split_rows(int batch, int P, int C2) {   // rows of the dgamma/dbeta workspace of mm_block_split_bwd
+  return ln_half_grid((int64_t)batch * P, C2 <= 128 ? 16 : 64) * 4;
+}
+
+int mm_block_split_fwd(const float* inp, const float* gamma, const float* beta, float eps, float* left_nchw, float* rn,
+                       float* mu, float* rstd, int batch, int P, int C2, void* stream) {
+  if (!inp || !gamma || !beta || !left_nchw || !rn || !mu || !rstd) return MM_ERR_NULL;
+  if (batch <= 0 || P <= 0 || C2 <= 0) return MM_ERR_SHAPE;
+  if (C2 > 8 * 64) return MM_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  const int C = 2 * C2;
+  const int64_t nrows = (int64_t)batch * P;
+  hipLaunchKernelGGL(half_transpose_kernel<false>, dim3(((P + 31) / 32) * ((C2 + 31) / 32) * batch), dim3(256), 0, s, inp, left_nchw, P, C, C2);
+  if (C2 <= 128) hipLaunchKernelGGL(ln_half_fwd_kernel<16>, dim3(ln_half_grid(nrows, 16)), dim3(256), 0, s, inp, gamma, beta, eps, rn, mu, rstd, nrows, C, C2);
+  else hipLaunchKernelGGL(ln_half_fwd_kernel<64>, dim3(ln_half_grid(nrows, 64)), dim3(256), 0, s, inp, gamma, beta, eps, rn, mu, rstd, nrows, C, C2);
+  return (int)hipGetLastError();
+}
+
+int mm_block_split_bwd(const float* dleft_nchw, const float* drn, const float* inp, const float* gamma, const float* mu,
+                       const float* rstd, float* dinp, float* ws, int batch, int P, int C2, void* stream) {
+  if (!dleft_nchw || !drn || !inp || !gamma || !mu || !rstd || !dinp || !ws) return MM_ERR_NULL;
+  if (batch <= 0 || P <= 0 || C2 <= 0) return MM_ERR_SHAPE;
+  if (C2 > 8 * 64) return MM_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  const int C = 2 * C2;
+  const int64_t nrows = (int64_t)batch * P;
+  hipLaunchKernelGGL(half_transpose_kernel<true>, dim3(((P + 31) / 32) * ((C2 + 31) / 32) * batch), dim3(256), 0, s, dleft_nchw, dinp, P, C, C2);
+  if (C2 <= 128) hipLaunchKernelGGL(ln_half_bwd_kernel<16>, dim3(ln_half_grid(nrows, 16)), dim3(256), 0, s, drn, inp, gamma, mu, rstd, dinp, ws, nrows, C, C2);
+  else hipLaunchKernelGGL(ln_half_bwd_kernel<64>, dim3(ln_half_grid(nrows, 64)), dim3(256), 0, s, drn, inp, gamma, mu, rstd, dinp, ws, nrows, C, C2);
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"

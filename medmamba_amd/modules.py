@@ -24,7 +24,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 import torch.utils.checkpoint as checkpoint
 
-from .ops import dwconv_silu_cross, shuffle_residual, ss2d_core
+from .ops import block_split, dwconv_silu_cross, shuffle_residual, ss2d_core
 from .selective_scan_interface import CROSS_SCAN_K_OF_G, cross_scan_fn, selective_scan_fn
 
 trunc_normal_ = nn.init.trunc_normal_   # timm.layers.trunc_normal_ == torch.nn.init.trunc_normal_
@@ -270,9 +270,14 @@ class SS_Conv_SSM(nn.Module):
         )
 
     def forward(self, input):
-        left, right = input.chunk(2, dim=-1)
-        x = self.drop_path(self.self_attention(self.ln_1(right)))
-        left = self.conv33conv33conv11(left.permute(0, 3, 1, 2).contiguous())            # stays NCHW
+        if isinstance(self.ln_1, nn.LayerNorm) and self.ln_1.elementwise_affine and self.ln_1.bias is not None:
+            # chunk + permute(0,3,1,2).contiguous() + ln_1 (MedMamba.py:350-352) in one fused HIP prologue
+            left, right_n = block_split(input, self.ln_1.weight, self.ln_1.bias, self.ln_1.eps)
+        else:                                                  # any other norm_layer: the reference's own op chain
+            left, right = input.chunk(2, dim=-1)
+            left, right_n = left.permute(0, 3, 1, 2).contiguous(), self.ln_1(right)
+        x = self.drop_path(self.self_attention(right_n))
+        left = self.conv33conv33conv11(left)                                                 # stays NCHW
         # permute back + cat + channel_shuffle(groups=2) + residual (MedMamba.py:354-357) fused in one HIP kernel
         return shuffle_residual(left, x, input)
 

@@ -163,3 +163,50 @@ def ss2d_core(u2, delta, A, Bm, Cm, Dp, dbias, z_cf, ln_w, ln_b, H, W, eps=1e-5)
     if A.shape[1] != 16 or Bm.shape[1] != 4 or delta.shape[1] != 2 * u2.shape[1]:
         raise NotImplementedError("ss2d_core: expects 4 directions, d_state 16, delta with 4*D channels")
     return SS2DCoreFn.apply(u2, delta, A, Bm, Cm, Dp, dbias, z_cf, ln_w, ln_b, H, W, eps)
+
+
+class BlockSplitFn(torch.autograd.Function):
+    """SS_Conv_SSM prologue (MedMamba.py:350-352): inp (B,H,W,C) -> (left NCHW (B,C/2,H,W), LayerNorm(right) (B,H,W,C/2)).
+    The backward writes both halves of d(inp) in place — no chunk/cat copies, no strided-LayerNorm copy."""
+
+    @staticmethod
+    def forward(ctx, inp, gamma, beta, eps):
+        inp = inp.float().contiguous()
+        gamma, beta = gamma.float().contiguous(), beta.float().contiguous()
+        B, H, W, C = inp.shape
+        C2, P = C // 2, H * W
+        dev = inp.device
+        left = torch.empty((B, C2, H, W), device=dev, dtype=torch.float32)
+        rn = torch.empty((B, H, W, C2), device=dev, dtype=torch.float32)
+        mu = torch.empty((B * P,), device=dev, dtype=torch.float32)
+        rstd = torch.empty((B * P,), device=dev, dtype=torch.float32)
+        with torch.cuda.device(dev):
+            rc = _lib.lib().mm_block_split_fwd(inp.data_ptr(), gamma.data_ptr(), beta.data_ptr(), float(eps), left.data_ptr(),
+                                               rn.data_ptr(), mu.data_ptr(), rstd.data_ptr(), B, P, C2, _stream())
+        _lib.check(rc, "mm_block_split_fwd")
+        ctx.save_for_backward(inp, gamma, mu, rstd)
+        return left, rn
+
+    @staticmethod
+    def backward(ctx, dleft, drn):
+        inp, gamma, mu, rstd = ctx.saved_tensors
+        B, H, W, C = inp.shape
+        C2, P = C // 2, H * W
+        dev = inp.device
+        dleft, drn = dleft.float().contiguous(), drn.float().contiguous()
+        dinp = torch.empty_like(inp)
+        lib = _lib.lib()
+        ws = torch.empty((lib.mm_block_split_rows(B, P, C2), 2 * C2), device=dev, dtype=torch.float32)
+        with torch.cuda.device(dev):
+            rc = lib.mm_block_split_bwd(dleft.data_ptr(), drn.data_ptr(), inp.data_ptr(), gamma.data_ptr(), mu.data_ptr(),
+                                        rstd.data_ptr(), dinp.data_ptr(), ws.data_ptr(), B, P, C2, _stream())
+        _lib.check(rc, "mm_block_split_bwd")
+        s = ws.sum(0)
+        return dinp, s[:C2].contiguous(), s[C2:].contiguous(), None
+
+
+def block_split(inp, gamma, beta, eps):
+    _need_hip(inp)
+    if inp.shape[-1] % 2 or inp.shape[-1] // 2 > 512:
+        raise NotImplementedError("block_split: even channel count <= 1024 expected")
+    return BlockSplitFn.apply(inp, gamma, beta, eps)

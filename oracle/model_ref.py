@@ -175,3 +175,9 @@ def ss2d_core_ref(u2, delta, A, Bm, Cm, Dp, dbias, z_cf, ln_w, ln_b, H, W, eps=1
     m = y2[:, 0] + y2[:, 1].reshape(B, D, W, H).transpose(2, 3).reshape(B, D, L)
     n = F.layer_norm(m.transpose(1, 2), (D,), ln_w, ln_b, eps).transpose(1, 2)
     return n * F.silu(z_cf)
+
+
+def block_split_ref(inp, gamma, beta, eps):
+    """Test double for medmamba_amd.ops.block_split: chunk + permute + ln_1 exactly as MedMamba.py:350-352."""
+    left, right = inp.chunk(2, dim=-1)
+    return left.permute(0, 3, 1, 2).contiguous(), F.layer_norm(right, (right.shape[-1],), gamma, beta, eps)

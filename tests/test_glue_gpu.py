@@ -80,3 +80,26 @@ def test_ss2d_core_forward_backward(shape):
     for n, a, b in zip(names, dev_in, ref_in):
         e = (a.grad.cpu() - b.grad).abs().max().item() / max(1.0, b.grad.abs().max().item())
         assert e <= 5e-4, (n, e)
+
+
+@pytest.mark.parametrize("shape", [(2, 5, 7, 16), (1, 56, 56, 96), (2, 14, 14, 384), (3, 7, 9, 66), (1, 4, 4, 1024)])
+def test_block_split_forward_backward(shape):
+    from medmamba_amd.ops import block_split
+    from oracle.model_ref import block_split_ref
+    B, H, W, C = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    inp = torch.randn(B, H, W, C, generator=g) * 2 + 0.5
+    gamma, beta = 1 + 0.2 * torch.randn(C // 2, generator=g), 0.2 * torch.randn(C // 2, generator=g)
+    dl, dr = torch.randn(B, C // 2, H, W, generator=g), torch.randn(B, H, W, C // 2, generator=g)
+    ri, rg_, rb = inp.clone().requires_grad_(), gamma.clone().requires_grad_(), beta.clone().requires_grad_()
+    l0, r0 = block_split_ref(ri, rg_, rb, 1e-5)
+    torch.autograd.backward([l0, r0], [dl, dr])
+    di, dg, db = inp.to(DEV).requires_grad_(), gamma.to(DEV).requires_grad_(), beta.to(DEV).requires_grad_()
+    l1, r1 = block_split(di, dg, db, 1e-5)
+    torch.autograd.backward([l1, r1], [dl.to(DEV), dr.to(DEV)])
+    assert torch.equal(l1.detach().cpu(), l0.detach())
+    close = lambda a, b, tol: (a.detach().cpu() - b.detach()).abs().max().item() <= tol * max(1.0, b.detach().abs().max().item())
+    assert close(r1, r0, 5e-6)
+    assert close(di.grad, ri.grad, 2e-5)
+    assert close(dg.grad, rg_.grad, 5e-5)
+    assert close(db.grad, rb.grad, 5e-5)

@@ -10,7 +10,7 @@ import torch
 
 from conftest import GOLDEN, load_golden, split_sd
 from medmamba_amd import modules as M
-from oracle.model_ref import dwconv_silu_cross_ref, shuffle_residual_ref, ss2d_core_ref
+from oracle.model_ref import block_split_ref, dwconv_silu_cross_ref, shuffle_residual_ref, ss2d_core_ref
 from oracle.scan_ref import c_cross_scan_fn, c_selective_scan_fn
 
 
@@ -21,6 +21,7 @@ def oracle_scan(monkeypatch):
     monkeypatch.setattr(M, "shuffle_residual", shuffle_residual_ref)
     monkeypatch.setattr(M, "dwconv_silu_cross", dwconv_silu_cross_ref)
     monkeypatch.setattr(M, "ss2d_core", ss2d_core_ref)
+    monkeypatch.setattr(M, "block_split", block_split_ref)
 
 
 def test_state_dict_layout_matches_reference_tiny():
