@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MM_ABI_VERSION 2
+#define MM_ABI_VERSION 4
 
 enum mm_status {
   MM_OK = 0,
@@ -97,6 +97,10 @@ typedef struct mm_scan_args {
   int32_t u_groups;
   uint32_t u_map;
   uint32_t rev_mask;
+  /* backward: element strides of dB / dC (batch, group, state); all zero = contiguous (batch, G, N, L).  Lets the caller
+   * receive dB/dC directly inside the gradient of x_dbl (MedMamba.py:261: B and C are row blocks of x_dbl). */
+  int64_t dB_sb, dB_sg, dB_sn;
+  int64_t dC_sb, dC_sg, dC_sn;
 } mm_scan_args;
 
 /* replaces selective_scan_cuda.fwd behind selective_scan_fn (MedMamba.py:273-279) */
@@ -108,12 +112,13 @@ int mm_scan_chunk(void);
 
 /* Block glue of SS_Conv_SSM.forward (MedMamba.py:354-357 + channel_shuffle :308-320), one pass over HBM:
  *   out[b,p,2i] = left[b,i,p] + inp[b,p,2i] ;  out[b,p,2i+1] = ssm[b,p,i] + inp[b,p,2i+1]
- * left: conv-branch output NCHW (batch, C2, P); ssm: SS2D-branch output NHWC (batch, P, C2);
- * inp, out: block input / output NHWC (batch, P, 2*C2); all contiguous fp32, P = H*W.
- * Backward: dleft (batch, C2, P) and dssm (batch, P, C2) from dout (batch, P, 2*C2); d(inp) = dout. */
+ * left: conv-branch output NCHW (batch, C2, P); ssm: SS2D-branch output, NHWC (batch, P, C2) or — ssm_channel_first != 0 —
+ * channel-first (batch, C2, P) like left; inp, out: block input / output NHWC (batch, P, 2*C2); contiguous fp32, P = H*W.
+ * Backward: dleft (batch, C2, P) and dssm (same layout as ssm) from dout (batch, P, 2*C2); d(inp) = dout. */
 int mm_shuffle_residual_fwd(const float* left, const float* ssm, const float* inp, float* out, int batch, int P, int C2,
+                            int ssm_channel_first, void* stream);
+int mm_shuffle_residual_bwd(const float* dout, float* dleft, float* dssm, int batch, int P, int C2, int ssm_channel_first,
                             void* stream);
-int mm_shuffle_residual_bwd(const float* dout, float* dleft, float* dssm, int batch, int P, int C2, void* stream);
 
 /* ---- SS2D in channel-first planes (everything between in_proj and out_proj is (batch, channel, H*W)) ----------
  * mm_dwconv_silu_cross_fwd: depthwise conv3x3 (pad 1) + bias + SiLU (MedMamba.py:153-162, 295) that writes the scan's

@@ -27,6 +27,8 @@ class ScanArgs(ctypes.Structure):
         ("dD", _f32p), ("ddelta_bias", _f32p),
         ("variant", ctypes.c_int32), ("u_groups", ctypes.c_int32), ("u_map", ctypes.c_uint32),
         ("rev_mask", ctypes.c_uint32),
+        ("dB_sb", ctypes.c_int64), ("dB_sg", ctypes.c_int64), ("dB_sn", ctypes.c_int64),
+        ("dC_sb", ctypes.c_int64), ("dC_sg", ctypes.c_int64), ("dC_sn", ctypes.c_int64),
     ]
 
 
@@ -37,7 +39,7 @@ SYMBOLS = {
     "mm_status_string": (ctypes.c_char_p, [ctypes.c_int]),
     "mm_scan_fwd": (ctypes.c_int, [ctypes.POINTER(ScanArgs), ctypes.c_void_p]),
     "mm_scan_bwd": (ctypes.c_int, [ctypes.POINTER(ScanArgs), ctypes.c_void_p]),
-    "mm_shuffle_residual_fwd": (ctypes.c_int, [_f32p] * 4 + [ctypes.c_int] * 3 + [ctypes.c_void_p]),
+    "mm_shuffle_residual_fwd": (ctypes.c_int, [_f32p] * 4 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
     "mm_dwconv_silu_cross_fwd": (ctypes.c_int, [_f32p, ctypes.c_int64, _f32p, _f32p, _f32p] + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
     "mm_dwconv_silu_cross_bwd": (ctypes.c_int, [_f32p, _f32p, ctypes.c_int64, _f32p, _f32p, _f32p, ctypes.c_int64, _f32p]
                                  + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
@@ -52,7 +54,7 @@ SYMBOLS = {
                            + [ctypes.c_void_p]),
     "mm_block_split_bwd": (ctypes.c_int, [_f32p] * 8 + [ctypes.c_int] * 3 + [ctypes.c_void_p]),
     "mm_block_split_rows": (ctypes.c_int, [ctypes.c_int] * 3),
-    "mm_shuffle_residual_bwd": (ctypes.c_int, [_f32p] * 3 + [ctypes.c_int] * 3 + [ctypes.c_void_p]),
+    "mm_shuffle_residual_bwd": (ctypes.c_int, [_f32p] * 3 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
 }
 
 _lib = None
@@ -77,7 +79,7 @@ def lib():
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(handle, name)      # AttributeError if the .so is stale
             fn.restype, fn.argtypes = res, args
-        if handle.mm_abi_version() != 2:
+        if handle.mm_abi_version() != 4:
             raise MedMambaHipError("libmedmamba_hip.so ABI version mismatch; rebuild")
         _lib = handle
     return _lib

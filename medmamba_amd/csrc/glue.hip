@@ -3,7 +3,7 @@
 // shuffle_residual: replaces  permute(0,2,3,1).contiguous() + cat + channel_shuffle(groups=2) + residual add
 //   (MedMamba.py:354-357; channel_shuffle :308-320):
 //     out[b,p,2i]   = left[b,i,p] + inp[b,p,2i]        left: conv-branch output, NCHW (b, C/2, P)
-//     out[b,p,2i+1] = ssm[b,p,i]  + inp[b,p,2i+1]      ssm : SS2D-branch output, NHWC (b, P, C/2)
+//     out[b,p,2i+1] = ssm[b,p,i]  + inp[b,p,2i+1]      ssm : SS2D-branch output, NHWC (b, P, C/2) or channel-first (b, C/2, P)
 //   The NCHW->NHWC transpose of `left` goes through a 32x33 LDS tile; all global accesses are 128-B runs.
 //   The backward is the same permutation read the other way (d_left, d_ssm from dout; d_inp = dout).
 #include "mm_common.h"
@@ -13,10 +13,12 @@ namespace {
 using namespace mm;
 
 // grid: (ceil(P/32), ceil(C2/32), B); block 256 = 8 rows x 32 lanes
+template <bool SSM_CF>
 __global__ __launch_bounds__(256) void shuffle_residual_fwd_kernel(const float* __restrict__ left, const float* __restrict__ ssm,
                                                                    const float* __restrict__ inp, float* __restrict__ out,
                                                                    int P, int C2) {
   __shared__ float tile[32][33];
+  __shared__ float tile2[SSM_CF ? 32 : 1][33];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const int p0 = blockIdx.x * 32, i0 = blockIdx.y * 32, b = blockIdx.z;
   const float* lb = left + (int64_t)b * C2 * P;
@@ -25,6 +27,7 @@ __global__ __launch_bounds__(256) void shuffle_residual_fwd_kernel(const float* 
   for (int r = ty; r < 32; r += 8) {
     const int i = i0 + r, p = p0 + tx;
     tile[r][tx] = (i < C2 && p < P) ? lb[(int64_t)i * P + p] : 0.f;
+    if constexpr (SSM_CF) tile2[r][tx] = (i < C2 && p < P) ? ssm[((int64_t)b * C2 + i) * P + p] : 0.f;
   }
   __syncthreads();
   // out rows: position p0+r, channel pair i0+tx (lanes along i)
@@ -34,15 +37,17 @@ __global__ __launch_bounds__(256) void shuffle_residual_fwd_kernel(const float* 
     const int p = p0 + r, i = i0 + tx;
     if (p < P && i < C2) {
       const float2 in2 = *reinterpret_cast<const float2*>(inp + ob + (int64_t)p * 2 * C2 + 2 * i);
-      const float s = ssm[((int64_t)b * P + p) * C2 + i];
+      const float s = SSM_CF ? tile2[tx][r] : ssm[((int64_t)b * P + p) * C2 + i];
       *reinterpret_cast<float2*>(out + ob + (int64_t)p * 2 * C2 + 2 * i) = make_float2(tile[tx][r] + in2.x, s + in2.y);
     }
   }
 }
 
+template <bool SSM_CF>
 __global__ __launch_bounds__(256) void shuffle_residual_bwd_kernel(const float* __restrict__ dout, float* __restrict__ dleft,
                                                                    float* __restrict__ dssm, int P, int C2) {
   __shared__ float tile[32][33];
+  __shared__ float tile2[SSM_CF ? 32 : 1][33];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const int p0 = blockIdx.x * 32, i0 = blockIdx.y * 32, b = blockIdx.z;
   const int64_t ob = (int64_t)b * P * (2 * C2);
@@ -52,16 +57,20 @@ __global__ __launch_bounds__(256) void shuffle_residual_bwd_kernel(const float* 
     float2 g = make_float2(0.f, 0.f);
     if (p < P && i < C2) {
       g = *reinterpret_cast<const float2*>(dout + ob + (int64_t)p * 2 * C2 + 2 * i);
-      dssm[((int64_t)b * P + p) * C2 + i] = g.y;
+      if constexpr (!SSM_CF) dssm[((int64_t)b * P + p) * C2 + i] = g.y;
     }
     tile[r][tx] = g.x;       // [p][i]
+    if constexpr (SSM_CF) tile2[r][tx] = g.y;
   }
   __syncthreads();
   float* lb = dleft + (int64_t)b * C2 * P;
 #pragma unroll
   for (int r = ty; r < 32; r += 8) {
     const int i = i0 + r, p = p0 + tx;
-    if (i < C2 && p < P) lb[(int64_t)i * P + p] = tile[tx][r];
+    if (i < C2 && p < P) {
+      lb[(int64_t)i * P + p] = tile[tx][r];
+      if constexpr (SSM_CF) dssm[((int64_t)b * C2 + i) * P + p] = tile2[tx][r];
+    }
   }
 }
 }  // namespace
@@ -69,21 +78,24 @@ __global__ __launch_bounds__(256) void shuffle_residual_bwd_kernel(const float* 
 extern "C" {
 
 int mm_shuffle_residual_fwd(const float* left, const float* ssm, const float* inp, float* out, int batch, int P, int C2,
-                            void* stream) {
+                            int ssm_channel_first, void* stream) {
   if (!left || !ssm || !inp || !out) return MM_ERR_NULL;
   if (batch <= 0 || P <= 0 || C2 <= 0 || batch > 65535) return MM_ERR_SHAPE;
   if ((reinterpret_cast<uintptr_t>(inp) | reinterpret_cast<uintptr_t>(out)) & 7) return MM_ERR_ALIGN;
   dim3 grid((P + 31) / 32, (C2 + 31) / 32, batch);
-  hipLaunchKernelGGL(shuffle_residual_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, left, ssm, inp, out, P, C2);
+  if (ssm_channel_first) hipLaunchKernelGGL(shuffle_residual_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, left, ssm, inp, out, P, C2);
+  else hipLaunchKernelGGL(shuffle_residual_fwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, left, ssm, inp, out, P, C2);
   return (int)hipGetLastError();
 }
 
-int mm_shuffle_residual_bwd(const float* dout, float* dleft, float* dssm, int batch, int P, int C2, void* stream) {
+int mm_shuffle_residual_bwd(const float* dout, float* dleft, float* dssm, int batch, int P, int C2, int ssm_channel_first,
+                            void* stream) {
   if (!dout || !dleft || !dssm) return MM_ERR_NULL;
   if (batch <= 0 || P <= 0 || C2 <= 0 || batch > 65535) return MM_ERR_SHAPE;
   if (reinterpret_cast<uintptr_t>(dout) & 7) return MM_ERR_ALIGN;
   dim3 grid((P + 31) / 32, (C2 + 31) / 32, batch);
-  hipLaunchKernelGGL(shuffle_residual_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, dout, dleft, dssm, P, C2);
+  if (ssm_channel_first) hipLaunchKernelGGL(shuffle_residual_bwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, dout, dleft, dssm, P, C2);
+  else hipLaunchKernelGGL(shuffle_residual_bwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, dout, dleft, dssm, P, C2);
   return (int)hipGetLastError();
 }
 

@@ -39,6 +39,7 @@ struct BwdParams {
   float* __restrict__ dD;
   float* __restrict__ dbias;
   int64_t u_sb, u_sd, d_sb, d_sd, B_sb, B_sg, B_sn, C_sb, C_sg, C_sn;
+  int64_t dB_sb, dB_sg, dB_sn, dC_sb, dC_sg, dC_sn;
   int dim, L, G, H, CW, ncw, ntiles, nchk;
   int ug;                   // channel blocks in u / dout
   unsigned u_map, rev_mask; // block of group g = (u_map >> 4g) & 15; bit g of rev_mask: group g runs backwards
@@ -110,8 +111,8 @@ __global__ __launch_bounds__(512) void scan_bwd_kernel(const BwdParams p) {
   const rsrc_t rdd = make_rsrc(p.ddelta + ((int64_t)b * p.dim + d0) * p.L, (int64_t)(p.dim - d0) * p.L * 4);
   const rsrc_t rB = make_rsrc(p.B + b * p.B_sb + grp * p.B_sg, ((int64_t)(kNState - 1) * p.B_sn + p.L) * 4);
   const rsrc_t rC = make_rsrc(p.C + b * p.C_sb + grp * p.C_sg, ((int64_t)(kNState - 1) * p.C_sn + p.L) * 4);
-  float* dBbase = p.dB + ((int64_t)b * p.G + grp) * kNState * p.L;
-  float* dCbase = p.dC + ((int64_t)b * p.G + grp) * kNState * p.L;
+  float* dBbase = p.dB + b * p.dB_sb + grp * p.dB_sg;
+  float* dCbase = p.dC + b * p.dC_sb + grp * p.dC_sg;
   bool rvalid[NLD];
   int uoff[NLD], doff[NLD], ooff[NLD];
   float bv[NLD], dDacc[NLD], dbacc[NLD];
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(512) void scan_bwd_kernel(const BwdParams p) {
       float* a = sAcc + ((buf * 2 + which) * kNState + n) * TS + 4 * qq;
       const float4 v = *reinterpret_cast<const float4*>(a);
       *reinterpret_cast<float4*>(a) = make_float4(0.f, 0.f, 0.f, 0.f);
-      float* dst = (which ? dCbase : dBbase) + (int64_t)n * p.L;
+      float* dst = which ? dCbase + n * p.dC_sn : dBbase + n * p.dB_sn;
       const int t = t0 + 4 * qq;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -372,6 +373,11 @@ int scan_bwd_launch(const mm_scan_args* a, hipStream_t stream) {
   p.u_sb = a->u_sb; p.u_sd = a->u_sd; p.d_sb = a->delta_sb; p.d_sd = a->delta_sd;
   p.B_sb = a->B_sb; p.B_sg = a->B_sg; p.B_sn = a->B_sn; p.C_sb = a->C_sb; p.C_sg = a->C_sg; p.C_sn = a->C_sn;
   p.dim = a->dim; p.L = a->L; p.G = a->G; p.H = a->dim / a->G;
+  const bool dbc_strided = a->dB_sb || a->dB_sg || a->dB_sn || a->dC_sb || a->dC_sg || a->dC_sn;
+  p.dB_sn = dbc_strided ? a->dB_sn : a->L;  p.dB_sg = dbc_strided ? a->dB_sg : (int64_t)kNState * a->L;
+  p.dB_sb = dbc_strided ? a->dB_sb : (int64_t)a->G * kNState * a->L;
+  p.dC_sn = dbc_strided ? a->dC_sn : a->L;  p.dC_sg = dbc_strided ? a->dC_sg : (int64_t)kNState * a->L;
+  p.dC_sb = dbc_strided ? a->dC_sb : (int64_t)a->G * kNState * a->L;
   p.ntiles = (a->L + T - 1) / T;
   p.nchk = (a->L + kChunk - 1) / kChunk;
   const bool shared = a->u_groups > 0 && a->u_groups < a->G;

@@ -24,7 +24,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 import torch.utils.checkpoint as checkpoint
 
-from .ops import block_split, dwconv_silu_cross, shuffle_residual, ss2d_core
+from .ops import block_split, dwconv_silu_cross, in_proj_cf, shuffle_residual, ss2d_core
 from .selective_scan_interface import CROSS_SCAN_K_OF_G, cross_scan_fn, selective_scan_fn
 
 trunc_normal_ = nn.init.trunc_normal_   # timm.layers.trunc_normal_ == torch.nn.init.trunc_normal_
@@ -197,52 +197,45 @@ class SS2D(nn.Module):
         and no un-flip exists (MedMamba.py:256-257, 282-286, 298); projections are plain batched GEMMs."""
         B, D, H, W = x.shape
         L, R, N = H * W, self.dt_rank, self.d_state
-        perm = list(CROSS_SCAN_K_OF_G)                      # kernel direction g -> reference direction k
+        pk = lambda t: torch.stack([t[k] for k in CROSS_SCAN_K_OF_G], dim=0)   # kernel direction g -> reference k
         u2 = x.new_empty(B, 2, D, L)
         u2[:, 0] = x.view(B, D, L)
         u2[:, 1].view(B, D, W, H).copy_(x.transpose(2, 3))
-        Wx = self.x_proj_weight[perm].reshape(1, 2, 2 * (R + 2 * N), D)
+        Wx = pk(self.x_proj_weight).reshape(1, 2, 2 * (R + 2 * N), D)
         x_dbl = torch.matmul(Wx, u2).view(B, 4, R + 2 * N, L)                              # :259
-        dts = torch.matmul(self.dt_projs_weight[perm].unsqueeze(0), x_dbl[:, :, :R])       # :262  (B,4,D,L)
+        dts = torch.matmul(pk(self.dt_projs_weight).unsqueeze(0), x_dbl[:, :, :R])         # :262  (B,4,D,L)
         y2 = cross_scan_fn(
             u2.view(B, 2 * D, L), dts.view(B, 4 * D, L),
-            -torch.exp(self.A_logs.float().view(4, D, N)[perm]).view(4 * D, N),
+            -torch.exp(pk(self.A_logs.float().view(4, D, N))).view(4 * D, N),
             x_dbl[:, :, R:R + N], x_dbl[:, :, R + N:],
-            self.Ds.float().view(4, D)[perm].reshape(-1), self.dt_projs_bias.float()[perm].reshape(-1)).view(B, 2, D, L)
+            pk(self.Ds.float().view(4, D)).reshape(-1), pk(self.dt_projs_bias.float()).reshape(-1)).view(B, 2, D, L)
         y = y2[:, 0].view(B, D, H, W).permute(0, 2, 3, 1) + y2[:, 1].view(B, D, W, H).permute(0, 3, 2, 1)
         return y.contiguous()
 
-    def forward(self, x, **kwargs):
-        """(B, H, W, d_model) -> (B, H, W, d_model).  MI355X layout: everything between in_proj and out_proj lives
-        in channel-first planes (B, channel, H*W): in_proj / out_proj are GEMMs with a transposed operand (no
-        copy), the depthwise conv, the scan, the cross-merge, out_norm and the gate are plane-wise HIP kernels, so
-        none of the reference's permute / stack / flip / transpose copies (MedMamba.py:294-299) exists."""
+    def forward_cf(self, x):
+        """(B, H, W, d_model) -> (B, d_model, H*W), channel-first.  MI355X layout: everything between in_proj and
+        out_proj lives in channel-first planes (B, channel, H*W): in_proj / out_proj are batched GEMMs with a broadcast
+        weight (no copy), the depthwise conv, the scan, the cross-merge, out_norm and the gate are plane-wise HIP
+        kernels, so none of the reference's permute / stack / flip / transpose copies (MedMamba.py:294-299) exists."""
         B, H, W, _ = x.shape
         L, D, R, N = H * W, self.d_inner, self.dt_rank, self.d_state
-        Xt = x.reshape(B, L, -1).transpose(1, 2)                                           # (B, d_model, L) view
-        Wi = self.in_proj.weight                                                             # (2D, d_model)
-        # batched GEMMs with a broadcast weight: the outputs come out channel-first and contiguous (a plain
-        # matmul would fold the batch, produce NHWC and hand back a transposed view)
-        x_cf = torch.bmm(Wi[:D].unsqueeze(0).expand(B, -1, -1), Xt)                          # :291-292, (B, D, L)
-        z_cf = torch.bmm(Wi[D:].unsqueeze(0).expand(B, -1, -1), Xt)
-        if self.in_proj.bias is not None:
-            x_cf = x_cf + self.in_proj.bias[:D, None]
-            z_cf = z_cf + self.in_proj.bias[D:, None]
+        x_cf, z_cf = in_proj_cf(x.reshape(B, L, -1), self.in_proj.weight, self.in_proj.bias)  # :291-292, (B, D, L) each
         u2 = dwconv_silu_cross(x_cf, self.conv2d.weight, self.conv2d.bias, H, W)            # :294-295 + :256
-        perm = list(CROSS_SCAN_K_OF_G)                       # kernel direction g -> reference direction k
-        Wx = self.x_proj_weight[perm].reshape(1, 2, 2 * (R + 2 * N), D)
-        x_dbl = torch.matmul(Wx, u2.view(B, 2, D, L)).view(B, 4, R + 2 * N, L)               # :259
-        dts = torch.matmul(self.dt_projs_weight[perm].unsqueeze(0), x_dbl[:, :, :R])         # :262
-        y_cf = ss2d_core(u2, dts.view(B, 4 * D, L),
-                         -torch.exp(self.A_logs.float().view(4, D, N)[perm]).view(4 * D, N),
-                         x_dbl[:, :, R:R + N], x_dbl[:, :, R + N:],
-                         self.Ds.float().view(4, D)[perm].reshape(-1), self.dt_projs_bias.float()[perm].reshape(-1),
+        # kernel direction g = (0,1,2,3) <-> reference direction k = (0,2,1,3): a 2x2 transpose of the leading dim
+        pk = lambda t: t.reshape(2, 2, *t.shape[1:]).transpose(0, 1).reshape(t.shape)
+        y_cf = ss2d_core(u2, pk(self.x_proj_weight), pk(self.dt_projs_weight),               # :259-262 inside
+                         -torch.exp(pk(self.A_logs.float().view(4, D, N))).view(4 * D, N),
+                         pk(self.Ds.float().view(4, D)).reshape(-1), pk(self.dt_projs_bias.float()).reshape(-1),
                          z_cf, self.out_norm.weight, self.out_norm.bias, H, W, self.out_norm.eps)   # :273-301
-        out = torch.bmm(y_cf.transpose(1, 2), self.out_proj.weight.t().unsqueeze(0).expand(B, -1, -1))   # :302, (B, L, d_model)
+        out = torch.bmm(self.out_proj.weight.unsqueeze(0).expand(B, -1, -1), y_cf)           # :302, (B, d_model, L)
         if self.out_proj.bias is not None:
-            out = out + self.out_proj.bias
-        out = out.view(B, H, W, -1)
+            out = out + self.out_proj.bias[:, None]
         return out if self.dropout is None else self.dropout(out)
+
+    def forward(self, x, **kwargs):
+        """(B, H, W, d_model) -> (B, H, W, d_model) (MedMamba.py:288-305)."""
+        B, H, W, _ = x.shape
+        return self.forward_cf(x).transpose(1, 2).reshape(B, H, W, -1)
 
 
 class SS_Conv_SSM(nn.Module):
@@ -276,10 +269,10 @@ class SS_Conv_SSM(nn.Module):
         else:                                                  # any other norm_layer: the reference's own op chain
             left, right = input.chunk(2, dim=-1)
             left, right_n = left.permute(0, 3, 1, 2).contiguous(), self.ln_1(right)
-        x = self.drop_path(self.self_attention(right_n))
+        x_cf = self.drop_path(self.self_attention.forward_cf(right_n))                       # (B, C/2, H*W)
         left = self.conv33conv33conv11(left)                                                 # stays NCHW
         # permute back + cat + channel_shuffle(groups=2) + residual (MedMamba.py:354-357) fused in one HIP kernel
-        return shuffle_residual(left, x, input)
+        return shuffle_residual(left, x_cf, input, channel_first=True)
 
 
 class VSSLayer(nn.Module):

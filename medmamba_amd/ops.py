@@ -16,18 +16,20 @@ def _need_hip(*ts):
 
 class ShuffleResidualFn(torch.autograd.Function):
     """out = channel_shuffle(cat(left_nhwc, ssm), 2) + inp   (MedMamba.py:354-357) in one kernel.
-    left: (B, C/2, H, W) NCHW conv-branch output; ssm: (B, H, W, C/2); inp: (B, H, W, C)."""
+    left: (B, C/2, H, W) NCHW conv-branch output; ssm: SS2D-branch output, (B, H, W, C/2) or — channel_first —
+    (B, C/2, H*W); inp: (B, H, W, C)."""
 
     @staticmethod
-    def forward(ctx, left, ssm, inp):
+    def forward(ctx, left, ssm, inp, channel_first):
         left, ssm, inp = left.float().contiguous(), ssm.float().contiguous(), inp.float().contiguous()
         B, C2, H, W = left.shape
         out = torch.empty_like(inp)
         with torch.cuda.device(inp.device):
             rc = _lib.lib().mm_shuffle_residual_fwd(left.data_ptr(), ssm.data_ptr(), inp.data_ptr(), out.data_ptr(),
-                                                    B, H * W, C2, _stream())
+                                                    B, H * W, C2, int(channel_first), _stream())
         _lib.check(rc, "mm_shuffle_residual_fwd")
         ctx.shape = (B, C2, H, W)
+        ctx.cf = bool(channel_first)
         return out
 
     @staticmethod
@@ -35,17 +37,56 @@ class ShuffleResidualFn(torch.autograd.Function):
         B, C2, H, W = ctx.shape
         dout = dout.float().contiguous()
         dleft = torch.empty((B, C2, H, W), device=dout.device, dtype=torch.float32)
-        dssm = torch.empty((B, H, W, C2), device=dout.device, dtype=torch.float32)
+        dssm = torch.empty((B, C2, H * W) if ctx.cf else (B, H, W, C2), device=dout.device, dtype=torch.float32)
         with torch.cuda.device(dout.device):
             rc = _lib.lib().mm_shuffle_residual_bwd(dout.data_ptr(), dleft.data_ptr(), dssm.data_ptr(), B, H * W, C2,
-                                                    _stream())
+                                                    int(ctx.cf), _stream())
         _lib.check(rc, "mm_shuffle_residual_bwd")
-        return dleft, dssm, dout
+        return dleft, dssm, dout, None
 
 
-def shuffle_residual(left_nchw, ssm_nhwc, inp_nhwc):
-    _need_hip(left_nchw, ssm_nhwc, inp_nhwc)
-    return ShuffleResidualFn.apply(left_nchw, ssm_nhwc, inp_nhwc)
+def shuffle_residual(left_nchw, ssm, inp_nhwc, channel_first=False):
+    _need_hip(left_nchw, ssm, inp_nhwc)
+    return ShuffleResidualFn.apply(left_nchw, ssm, inp_nhwc, channel_first)
+
+
+class InProjFn(torch.autograd.Function):
+    """SS2D.in_proj (MedMamba.py:291-292) producing the two channel-first halves without any slicing in autograd:
+    x (B, L, d_model) NHWC rows, weight (2D, d_model)[, bias (2D)] -> (x_cf, z_cf) = two (B, D, L) views of one buffer.
+    The backward consumes both gradients directly (no zero-fill / copy / add of sliced activations or weights)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        Bsz, L, dm = x.shape
+        D = weight.shape[0] // 2
+        xz = torch.bmm(weight.unsqueeze(0).expand(Bsz, -1, -1), x.transpose(1, 2))          # (B, 2D, L)
+        if bias is not None:
+            xz += bias[:, None]
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return xz[:, :D], xz[:, D:]
+
+    @staticmethod
+    def backward(ctx, dx_cf, dz_cf):
+        x, weight = ctx.saved_tensors
+        Bsz, L, dm = x.shape
+        D = weight.shape[0] // 2
+        w0, w1 = weight[:D], weight[D:]
+        # d x (B, L, dm) = dx_cf^T @ W[:D] + dz_cf^T @ W[D:]
+        dx = torch.bmm(dx_cf.transpose(1, 2), w0.unsqueeze(0).expand(Bsz, -1, -1))
+        dx.baddbmm_(dz_cf.transpose(1, 2), w1.unsqueeze(0).expand(Bsz, -1, -1))
+        dw = torch.empty_like(weight)
+        torch.sum(torch.bmm(dx_cf, x), dim=0, out=dw[:D])
+        torch.sum(torch.bmm(dz_cf, x), dim=0, out=dw[D:])
+        db = None
+        if ctx.has_bias:
+            db = torch.cat([dx_cf.sum(dim=(0, 2)), dz_cf.sum(dim=(0, 2))])
+        return dx, dw, db
+
+
+def in_proj_cf(x_rows, weight, bias):
+    _need_hip(x_rows, weight)
+    return InProjFn.apply(x_rows, weight, bias)
 
 
 class DwConvSiluCrossFn(torch.autograd.Function):
@@ -95,20 +136,33 @@ def dwconv_silu_cross(x_cf, weight, bias, H, W):
 
 
 class SS2DCoreFn(torch.autograd.Function):
-    """4-direction selective scan + cross-merge + out_norm LayerNorm + SiLU(z) gate in channel-first planes
-    (MedMamba.py:273-286, 298-301).  Inputs as cross_scan_fn plus z_cf (B, D, L), LayerNorm weight/bias/eps and the
-    image size; returns y_cf (B, D, L) = LN_D(merge(scan(...))) * silu(z).
-    Saved for backward: the scan operands + checkpoints, the merged pre-norm tensor m (B,D,L) and the LN statistics;
-    the (B,4D,L) scan output is freed after the merge."""
+    """x/dt projections + 4-direction selective scan + cross-merge + out_norm LayerNorm + SiLU(z) gate in channel-first
+    planes (MedMamba.py:259-262, 273-286, 298-301).
+
+    u2 (B, 2D, L): row-major | column-major image (dwconv_silu_cross);  Wx (4, R+2N, D), Wdt (4, D, R), A (4D, N),
+    Dp, dbias (4D) — all in KERNEL direction order (row-major fwd/rev, column-major fwd/rev);  z_cf (B, D, L);
+    LayerNorm weight / bias / eps; image size.  Returns y_cf (B, D, L) = LN_D(merge(scan(...))) * silu(z).
+
+    The projections live inside the Function so that autograd never slices x_dbl: the backward kernel writes dB / dC
+    straight into the row blocks of d(x_dbl) (strided outputs of mm_scan_bwd), the dt rows are filled by one GEMM, and
+    d(u2) collects its three contributions (two direction pairs + the x projection) with one add and one GEMM
+    (beta = 1).  Saved: u2, x_dbl, delta, the state checkpoints, the merged pre-norm tensor m and the LN statistics;
+    the (B, 4D, L) scan output is freed after the merge."""
 
     @staticmethod
-    def forward(ctx, u2, delta, A, Bm, Cm, Dp, dbias, z_cf, ln_w, ln_b, H, W, eps):
-        from .selective_scan_interface import _CROSS_SHARED, _launch_fwd, _prep
-        u2, delta, A, Bm, Cm, Dp, dbias = _prep(u2, delta, A, Bm, Cm, Dp, dbias)
-        Bsz, D4, L = delta.shape
-        D = D4 // 4
+    def forward(ctx, u2, Wx, Wdt, A, Dp, dbias, z_cf, ln_w, ln_b, H, W, eps):
+        from .selective_scan_interface import _CROSS_SHARED, _launch_fwd
+        Bsz, D2, L = u2.shape
+        D, R, N = D2 // 2, Wdt.shape[2], A.shape[1]
+        C = R + 2 * N
+        u2 = u2.float().contiguous()
+        Wx, Wdt, A = Wx.float().contiguous(), Wdt.float().contiguous(), A.float().contiguous()
+        Dp, dbias = Dp.float().contiguous(), dbias.float().contiguous()
+        x_dbl = torch.matmul(Wx.view(1, 2, 2 * C, D), u2.view(Bsz, 2, D, L)).view(Bsz, 4, C, L)        # :259
+        delta = torch.matmul(Wdt.unsqueeze(0), x_dbl[:, :, :R]).view(Bsz, 4 * D, L)                    # :262
         need_grad = any(ctx.needs_input_grad)
-        out4, x_chk = _launch_fwd(u2, delta, A, Bm, Cm, Dp, dbias, True, need_grad, 0, _CROSS_SHARED)
+        out4, x_chk = _launch_fwd(u2, delta, A, x_dbl[:, :, R:R + N], x_dbl[:, :, R + N:], Dp, dbias, True, need_grad, 0,
+                                  _CROSS_SHARED)
         z_cf = z_cf.float()
         if z_cf.stride(2) != 1 or z_cf.stride(1) != L:
             z_cf = z_cf.contiguous()
@@ -126,23 +180,24 @@ class SS2DCoreFn(torch.autograd.Function):
                                     y.data_ptr(), mu.data_ptr(), rstd.data_ptr(), Bsz, D, L, _stream())
             _lib.check(rc, "mm_ln_gate_fwd")
         if need_grad:
-            ctx.save_for_backward(u2, delta, A, Bm, Cm, Dp, dbias, x_chk, m, mu, rstd, z_cf, ln_w, ln_b)
+            ctx.save_for_backward(u2, x_dbl, delta, Wx, Wdt, A, Dp, dbias, x_chk, m, mu, rstd, z_cf, ln_w, ln_b)
             ctx.hw = (H, W)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         from .selective_scan_interface import _CROSS_SHARED, _launch_bwd
-        u2, delta, A, Bm, Cm, Dp, dbias, x_chk, m, mu, rstd, z_cf, ln_w, ln_b = ctx.saved_tensors
+        u2, x_dbl, delta, Wx, Wdt, A, Dp, dbias, x_chk, m, mu, rstd, z_cf, ln_w, ln_b = ctx.saved_tensors
         H, W = ctx.hw
         Bsz, D, L = m.shape
+        R, N = Wdt.shape[2], A.shape[1]
+        C = R + 2 * N
         dev = m.device
         dy = dy.float().contiguous()
         dout2 = torch.empty((Bsz, 2 * D, L), device=dev, dtype=torch.float32)    # block 0: dm, block 1: its plane transpose
         dz = torch.empty((Bsz, D, L), device=dev, dtype=torch.float32)
         lib = _lib.lib()
-        rows = lib.mm_ln_gate_rows(Bsz, L)
-        ws = torch.empty((rows, 2 * D), device=dev, dtype=torch.float32)
+        ws = torch.empty((lib.mm_ln_gate_rows(Bsz, L), 2 * D), device=dev, dtype=torch.float32)
         with torch.cuda.device(dev):
             rc = lib.mm_ln_gate_bwd(dy.data_ptr(), m.data_ptr(), z_cf.data_ptr(), z_cf.stride(0), ln_w.data_ptr(), ln_b.data_ptr(),
                                     mu.data_ptr(), rstd.data_ptr(), dout2.data_ptr(), dout2.stride(0), dz.data_ptr(),
@@ -152,17 +207,30 @@ class SS2DCoreFn(torch.autograd.Function):
                                         Bsz, D, H, W, _stream())
             _lib.check(rc, "mm_plane_transpose")
         wsum = ws.sum(0)
-        du4, ddelta, dA, dB, dC, dD, ddb = _launch_bwd(u2, delta, A, Bm, Cm, Dp, dbias, x_chk, dout2, True, _CROSS_SHARED)
+        dx_dbl = torch.zeros((Bsz, 4, C, L), device=dev, dtype=torch.float32)    # dB/dC are accumulated (atomics for D > 128)
+        du4, ddelta, dA, _, _, dD, ddb = _launch_bwd(u2, delta, A, x_dbl[:, :, R:R + N], x_dbl[:, :, R + N:], Dp, dbias, x_chk,
+                                                    dout2, True, _CROSS_SHARED,
+                                                    dBC=(dx_dbl[:, :, R:R + N], dx_dbl[:, :, R + N:]))
+        dd = ddelta.view(Bsz, 4, D, L)
+        xr = x_dbl[:, :, :R]
+        dWdt = torch.matmul(dd, xr.transpose(-1, -2)).sum(0)                                  # (4, D, R)
+        dx_dbl[:, :, :R] = torch.matmul(Wdt.transpose(-1, -2).unsqueeze(0), dd)               # dt rows of d(x_dbl)
         d4 = du4.view(Bsz, 2, 2, D, L)
-        du2 = (d4[:, :, 0] + d4[:, :, 1]).view(Bsz, 2 * D, L)
-        return du2, ddelta, dA, dB, dC, dD, ddb, dz, wsum[:D].contiguous(), wsum[D:].contiguous(), None, None, None
+        du2 = (d4[:, :, 0] + d4[:, :, 1]).view(Bsz * 2, D, L)                                 # the two directions of a pair
+        Wx2 = Wx.view(2, 2 * C, D)
+        dxd2 = dx_dbl.view(Bsz, 2, 2 * C, L)
+        du2.baddbmm_(Wx2.transpose(1, 2).unsqueeze(0).expand(Bsz, -1, -1, -1).reshape(Bsz * 2, D, 2 * C),
+                     dxd2.reshape(Bsz * 2, 2 * C, L))                                       # + Wx^T d(x_dbl)
+        dWx = torch.matmul(dxd2, u2.view(Bsz, 2, D, L).transpose(-1, -2)).sum(0).view(4, C, D)
+        return (du2.view(Bsz, 2 * D, L), dWx, dWdt, dA, dD, ddb, dz, wsum[:D].contiguous(), wsum[D:].contiguous(),
+                None, None, None)
 
 
-def ss2d_core(u2, delta, A, Bm, Cm, Dp, dbias, z_cf, ln_w, ln_b, H, W, eps=1e-5):
-    _need_hip(u2, delta, z_cf)
-    if A.shape[1] != 16 or Bm.shape[1] != 4 or delta.shape[1] != 2 * u2.shape[1]:
-        raise NotImplementedError("ss2d_core: expects 4 directions, d_state 16, delta with 4*D channels")
-    return SS2DCoreFn.apply(u2, delta, A, Bm, Cm, Dp, dbias, z_cf, ln_w, ln_b, H, W, eps)
+def ss2d_core(u2, Wx, Wdt, A, Dp, dbias, z_cf, ln_w, ln_b, H, W, eps=1e-5):
+    _need_hip(u2, z_cf)
+    if A.shape[1] != 16 or Wx.shape[0] != 4 or Wdt.shape[0] != 4 or A.shape[0] != 2 * u2.shape[1]:
+        raise NotImplementedError("ss2d_core: expects 4 directions, d_state 16, u2 with 2*D channels")
+    return SS2DCoreFn.apply(u2, Wx, Wdt, A, Dp, dbias, z_cf, ln_w, ln_b, H, W, eps)
 
 
 class BlockSplitFn(torch.autograd.Function):

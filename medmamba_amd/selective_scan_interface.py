@@ -130,16 +130,22 @@ def _launch_fwd(u, delta, A, B, C, D, delta_bias, delta_softplus, want_chk, vari
     return out, x_chk
 
 
-def _launch_bwd(u, delta, A, B, C, D, delta_bias, x_chk, dout, delta_softplus, shared=(0, 0, 0)):
-    """mm_scan_bwd on torch's current stream. Returns du (per group), ddelta, dA, dB, dC, dD, dbias."""
+def _launch_bwd(u, delta, A, B, C, D, delta_bias, x_chk, dout, delta_softplus, shared=(0, 0, 0), dBC=None):
+    """mm_scan_bwd on torch's current stream. Returns du (per group), ddelta, dA, dB, dC, dD, dbias.
+    dBC: optional (dB_view, dC_view) — zero-filled (batch, G, N, L) views (unit stride along L) to accumulate into,
+    e.g. row blocks of the gradient of x_dbl."""
     batch, dim, L = delta.shape
     G, N = B.shape[1], A.shape[1]
     dev = u.device
     du, ddelta = torch.empty_like(delta), torch.empty_like(delta)
     # accumulated with atomics across batch / channel tiles -> zero-filled here (header contract)
     dA = torch.zeros((dim, N), device=dev, dtype=torch.float32)
-    dB = torch.zeros((batch, G, N, L), device=dev, dtype=torch.float32)
-    dC = torch.zeros((batch, G, N, L), device=dev, dtype=torch.float32)
+    if dBC is None:
+        dB = torch.zeros((batch, G, N, L), device=dev, dtype=torch.float32)
+        dC = torch.zeros((batch, G, N, L), device=dev, dtype=torch.float32)
+    else:
+        dB, dC = dBC
+        assert dB.stride(3) == 1 and dC.stride(3) == 1 and dB.shape == (batch, G, N, L) == dC.shape
     dD = None if D is None else torch.zeros((dim,), device=dev, dtype=torch.float32)
     dbias = None if delta_bias is None else torch.zeros((dim,), device=dev, dtype=torch.float32)
     a = _lib.ScanArgs()
@@ -149,6 +155,9 @@ def _launch_bwd(u, delta, A, B, C, D, delta_bias, x_chk, dout, delta_softplus, s
     a.dD, a.ddelta_bias = _ptr(dD), _ptr(dbias)
     a.u_groups, a.u_map, a.rev_mask = shared
     a.variant = _BWD_VARIANT
+    if dBC is not None:
+        a.dB_sb, a.dB_sg, a.dB_sn = dB.stride(0), dB.stride(1), dB.stride(2)
+        a.dC_sb, a.dC_sg, a.dC_sn = dC.stride(0), dC.stride(1), dC.stride(2)
     with torch.cuda.device(dev):
         t0 = KERNEL_TIMER.start()
         rc = _lib.lib().mm_scan_bwd(a, torch.cuda.current_stream().cuda_stream)

@@ -152,10 +152,20 @@ def dt_rank(dim):
     return math.ceil((dim // 2) / 16)
 
 
-def shuffle_residual_ref(left_nchw, ssm_nhwc, inp_nhwc):
-    """Test double for medmamba_amd.ops.shuffle_residual: the reference's own op chain, MedMamba.py:354-357."""
+def shuffle_residual_ref(left_nchw, ssm, inp_nhwc, channel_first=False):
+    """Test double for medmamba_amd.ops.shuffle_residual: the reference's own op chain, MedMamba.py:354-357.
+    channel_first: ssm is (B, C/2, H*W) instead of (B, H, W, C/2)."""
     left = left_nchw.permute(0, 2, 3, 1).contiguous()
-    return channel_shuffle(torch.cat((left, ssm_nhwc), dim=-1), 2) + inp_nhwc
+    if channel_first:
+        ssm = ssm.transpose(1, 2).reshape(left.shape)
+    return channel_shuffle(torch.cat((left, ssm), dim=-1), 2) + inp_nhwc
+
+
+def in_proj_cf_ref(x_rows, weight, bias):
+    """Test double for medmamba_amd.ops.in_proj_cf: in_proj + chunk (MedMamba.py:291-292), returned channel-first."""
+    xz = F.linear(x_rows, weight, bias).transpose(1, 2)
+    D = weight.shape[0] // 2
+    return xz[:, :D], xz[:, D:]
 
 
 def dwconv_silu_cross_ref(x_cf, weight, bias, H, W):
@@ -165,13 +175,17 @@ def dwconv_silu_cross_ref(x_cf, weight, bias, H, W):
     return torch.stack([xc.reshape(B, D, L), xc.transpose(2, 3).reshape(B, D, L)], 1).reshape(B, 2 * D, L)
 
 
-def ss2d_core_ref(u2, delta, A, Bm, Cm, Dp, dbias, z_cf, ln_w, ln_b, H, W, eps=1e-5):
-    """Test double for medmamba_amd.ops.ss2d_core: oracle scan (explicit flips) + the reference's merge (:282-286, 298),
-    out_norm (:300) and gate (:301), kept channel-first."""
+def ss2d_core_ref(u2, Wx, Wdt, A, Dp, dbias, z_cf, ln_w, ln_b, H, W, eps=1e-5):
+    """Test double for medmamba_amd.ops.ss2d_core: the x / dt projections (MedMamba.py:259-262) as einsums, the oracle scan
+    on explicitly flipped tensors, the reference's merge (:282-286, 298), out_norm (:300) and gate (:301), channel-first.
+    Weights are given in kernel direction order (row-major fwd/rev, column-major fwd/rev)."""
     from .scan_ref import c_cross_scan_fn
     B, D2, L = u2.shape
-    D = D2 // 2
-    y2 = c_cross_scan_fn(u2, delta, A, Bm, Cm, Dp, dbias).view(B, 2, D, L)
+    D, R, N = D2 // 2, Wdt.shape[2], A.shape[1]
+    u4 = u2.view(B, 2, 1, D, L).expand(B, 2, 2, D, L).reshape(B, 4, D, L)           # direction g reads block g // 2
+    x_dbl = torch.einsum("bgdl,gcd->bgcl", u4, Wx)
+    delta = torch.einsum("bgrl,gdr->bgdl", x_dbl[:, :, :R], Wdt).reshape(B, 4 * D, L)
+    y2 = c_cross_scan_fn(u2, delta, A, x_dbl[:, :, R:R + N], x_dbl[:, :, R + N:], Dp, dbias).view(B, 2, D, L)
     m = y2[:, 0] + y2[:, 1].reshape(B, D, W, H).transpose(2, 3).reshape(B, D, L)
     n = F.layer_norm(m.transpose(1, 2), (D,), ln_w, ln_b, eps).transpose(1, 2)
     return n * F.silu(z_cf)

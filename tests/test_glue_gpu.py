@@ -27,6 +27,34 @@ def test_shuffle_residual_forward_backward(shape):
     assert torch.equal(out.detach().cpu(), ref.detach())            # one fp32 add per element: bit-exact
     for a, b in zip(dev_in, ref_in):
         assert torch.equal(a.grad.cpu(), b.grad)
+    # channel-first SS2D branch (B, C/2, H*W): same values, transposed layout in and out
+    ssm_cf = ssm.reshape(B, H * W, C2).transpose(1, 2).contiguous()
+    dev_cf = [left.to(DEV).requires_grad_(), ssm_cf.to(DEV).requires_grad_(), inp.to(DEV).requires_grad_()]
+    out_cf = shuffle_residual(*dev_cf, channel_first=True)
+    out_cf.backward(dout.to(DEV))
+    assert torch.equal(out_cf.detach().cpu(), ref.detach())
+    assert torch.equal(dev_cf[1].grad.cpu(), ref_in[1].grad.reshape(B, H * W, C2).transpose(1, 2))
+    assert torch.equal(dev_cf[0].grad.cpu(), ref_in[0].grad)
+
+
+def test_in_proj_cf_forward_backward():
+    from medmamba_amd.ops import in_proj_cf
+    from oracle.model_ref import in_proj_cf_ref
+    g = torch.Generator().manual_seed(3)
+    B, L, dm, D = 3, 50, 24, 48
+    x, w, bias = torch.randn(B, L, dm, generator=g), torch.randn(2 * D, dm, generator=g), torch.randn(2 * D, generator=g)
+    gx, gz = torch.randn(B, D, L, generator=g), torch.randn(B, D, L, generator=g)
+    for use_bias in (False, True):
+        r = [t.clone().requires_grad_() for t in (x, w, bias)]
+        a0, b0 = in_proj_cf_ref(r[0], r[1], r[2] if use_bias else None)
+        torch.autograd.backward([a0, b0], [gx, gz])
+        d = [t.to(DEV).requires_grad_() for t in (x, w, bias)]
+        a1, b1 = in_proj_cf(d[0], d[1], d[2] if use_bias else None)
+        torch.autograd.backward([a1, b1], [gx.to(DEV), gz.to(DEV)])
+        close = lambda p, q: (p.detach().cpu() - q.detach()).abs().max().item() <= 2e-5 * max(1.0, q.detach().abs().max().item())
+        assert close(a1, a0) and close(b1, b0)
+        for p, q in list(zip(d, r))[: 3 if use_bias else 2]:
+            assert close(p.grad, q.grad)
 
 
 @pytest.mark.parametrize("shape", [(2, 8, 5, 7), (1, 96, 56, 56), (2, 16, 14, 14), (3, 5, 7, 7), (1, 4, 33, 40)])
@@ -52,22 +80,23 @@ def test_dwconv_silu_cross_forward_backward(shape):
     assert close(bd.grad, br.grad, 2e-5)
 
 
-@pytest.mark.parametrize("shape", [(2, 8, 5, 7), (1, 24, 14, 14), (2, 16, 9, 4), (1, 8, 33, 36)])
+@pytest.mark.parametrize("shape", [(2, 8, 5, 7, 1), (1, 24, 14, 14, 2), (2, 16, 9, 4, 3), (1, 8, 33, 36, 1), (1, 160, 6, 6, 5)])
 def test_ss2d_core_forward_backward(shape):
-    """scan + cross-merge + out_norm + gate (channel-first HIP path) vs the oracle chain (explicit flips, torch LN)."""
+    """projections + scan + cross-merge + out_norm + gate (channel-first HIP path) vs the oracle chain (einsums, explicit
+    flips, torch LN).  The last shape has D > 128: a direction is split over several backward workgroups (atomics)."""
     from medmamba_amd.ops import ss2d_core
     from oracle.model_ref import ss2d_core_ref
-    B, D, H, W = shape
+    B, D, H, W, R = shape
     L, N = H * W, 16
     g = torch.Generator().manual_seed(sum(shape))
     mk = lambda *s: torch.randn(*s, generator=g)
-    u2, delta = mk(B, 2 * D, L), mk(B, 4 * D, L)
+    u2 = mk(B, 2 * D, L)
+    Wx, Wdt = mk(4, R + 2 * N, D) / D ** 0.5, mk(4, D, R) / R ** 0.5
     A = -torch.exp(mk(4 * D, N) * 0.5)
-    Bm, Cm = mk(B, 4, N, L), mk(B, 4, N, L)
     Dp, dbias = mk(4 * D), mk(4 * D) - 3
     z, lw, lb = mk(B, D, L), 1 + 0.1 * mk(D), 0.1 * mk(D)
     dy = mk(B, D, L)
-    leaves = (u2, delta, A, Bm, Cm, Dp, dbias, z, lw, lb)
+    leaves = (u2, Wx, Wdt, A, Dp, dbias, z, lw, lb)
     ref_in = [t.clone().requires_grad_() for t in leaves]
     ref = ss2d_core_ref(*ref_in, H, W, 1e-5)
     ref.backward(dy)
@@ -76,7 +105,7 @@ def test_ss2d_core_forward_backward(shape):
     out.backward(dy.to(DEV))
     err = (out.detach().cpu() - ref.detach()).abs().max().item()
     assert err <= 5e-5 * max(1.0, ref.detach().abs().max().item()), err
-    names = ["du2", "ddelta", "dA", "dB", "dC", "dD", "dbias", "dz", "dln_w", "dln_b"]
+    names = ["du2", "dWx", "dWdt", "dA", "dD", "dbias", "dz", "dln_w", "dln_b"]
     for n, a, b in zip(names, dev_in, ref_in):
         e = (a.grad.cpu() - b.grad).abs().max().item() / max(1.0, b.grad.abs().max().item())
         assert e <= 5e-4, (n, e)
