@@ -29,6 +29,16 @@ from .selective_scan_interface import CROSS_SCAN_K_OF_G, cross_scan_fn, selectiv
 
 trunc_normal_ = nn.init.trunc_normal_   # timm.layers.trunc_normal_ == torch.nn.init.trunc_normal_
 
+_TWO_STREAMS = __import__("os").environ.get("MM_TWO_STREAMS", "1") == "1"   # MM_TWO_STREAMS=0: single-stream blocks
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    s = _SIDE_STREAMS.get(device)
+    if s is None:
+        s = _SIDE_STREAMS[device] = torch.cuda.Stream(device=device)
+    return s
+
 
 class DropPath(nn.Module):
     """Per-sample stochastic depth (timm.layers.DropPath semantics; MedMamba.py:335)."""
@@ -269,8 +279,21 @@ class SS_Conv_SSM(nn.Module):
         else:                                                  # any other norm_layer: the reference's own op chain
             left, right = input.chunk(2, dim=-1)
             left, right_n = left.permute(0, 3, 1, 2).contiguous(), self.ln_1(right)
-        x_cf = self.drop_path(self.self_attention.forward_cf(right_n))                       # (B, C/2, H*W)
-        left = self.conv33conv33conv11(left)                                                 # stays NCHW
+        if _TWO_STREAMS and input.is_cuda:
+            # the conv branch and the SS2D branch are independent (MedMamba.py:351-353): run the conv branch on a side
+            # HIP stream so that its MIOpen kernels overlap the scan (autograd replays the backward on the same streams)
+            main = torch.cuda.current_stream()
+            side = _side_stream(input.device)
+            side.wait_stream(main)
+            left.record_stream(side)       # allocated on `main`, read by the side stream in forward and backward
+            with torch.cuda.stream(side):
+                left = self.conv33conv33conv11(left)                                         # stays NCHW
+            x_cf = self.drop_path(self.self_attention.forward_cf(right_n))                   # (B, C/2, H*W)
+            main.wait_stream(side)
+            left.record_stream(main)
+        else:
+            x_cf = self.drop_path(self.self_attention.forward_cf(right_n))                   # (B, C/2, H*W)
+            left = self.conv33conv33conv11(left)                                             # stays NCHW
         # permute back + cat + channel_shuffle(groups=2) + residual (MedMamba.py:354-357) fused in one HIP kernel
         return shuffle_residual(left, x_cf, input, channel_first=True)
 

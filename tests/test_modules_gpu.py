@@ -88,3 +88,32 @@ def test_seed_kat_full_model_logits(size):
     with torch.no_grad():
         logits = net.to(DEV)(x.to(DEV))
     _close(logits[0], np.array(kat["logits"]), 1e-3, "logits")     # logits atol 1e-3
+
+
+def test_two_stream_blocks_match_single_stream(monkeypatch):
+    """The conv branch runs on a side HIP stream (modules.SS_Conv_SSM.forward): same loss and grads as the
+    single-stream schedule, run after run with the allocator churned in between (a missed cross-stream dependency or
+    an early buffer reuse shows here).  Weights stay fixed: with optimizer steps in between, the 1e-7 run-to-run
+    noise of the atomics flips ReLU masks and the comparison turns chaotic in either schedule."""
+    from medmamba_amd import modules
+    torch.manual_seed(3)
+    net = modules.VSSM(num_classes=5, depths=[2, 2, 2, 2], dims=[32, 64, 128, 256], drop_path_rate=0.0).to(DEV).train()
+    x = torch.randn(8, 3, 128, 128, device=DEV)
+    y = torch.randint(0, 5, (8,), device=DEV)
+
+    def run(two, it):
+        monkeypatch.setattr(modules, "_TWO_STREAMS", two)
+        net.zero_grad(set_to_none=True)
+        junk = [torch.empty(1 << (16 + (it + j) % 6), device=DEV).normal_() for j in range(4)]   # churn the allocator
+        loss = torch.nn.functional.cross_entropy(net(x), y)
+        loss.backward()
+        del junk
+        return float(loss.detach()), {k: p.grad.clone() for k, p in net.named_parameters()}
+
+    l0, g0 = run(False, 0)
+    for it, two in enumerate([True, True, False, True, True, True], start=1):
+        l, g = run(two, it)
+        assert abs(l - l0) <= 1e-6 * abs(l0), (it, l, l0)
+        for k in g0:
+            scale = max(1e-4, float(g0[k].abs().max()))
+            assert float((g0[k] - g[k]).abs().max()) <= 2e-3 * scale, (it, two, k)
