@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MM_ABI_VERSION 4
+#define MM_ABI_VERSION 5
 
 enum mm_status {
   MM_OK = 0,
@@ -114,11 +114,15 @@ int mm_scan_chunk(void);
  *   out[b,p,2i] = left[b,i,p] + inp[b,p,2i] ;  out[b,p,2i+1] = ssm[b,p,i] + inp[b,p,2i+1]
  * left: conv-branch output NCHW (batch, C2, P); ssm: SS2D-branch output, NHWC (batch, P, C2) or — ssm_channel_first != 0 —
  * channel-first (batch, C2, P) like left; inp, out: block input / output NHWC (batch, P, 2*C2); contiguous fp32, P = H*W.
- * Backward: dleft (batch, C2, P) and dssm (same layout as ssm) from dout (batch, P, 2*C2); d(inp) = dout. */
-int mm_shuffle_residual_fwd(const float* left, const float* ssm, const float* inp, float* out, int batch, int P, int C2,
-                            int ssm_channel_first, void* stream);
-int mm_shuffle_residual_bwd(const float* dout, float* dleft, float* dssm, int batch, int P, int C2, int ssm_channel_first,
-                            void* stream);
+ * Two neighbours of the chain are folded in (both optional):
+ *   left_relu != 0 : `left` is the PRE-activation of the conv branch's trailing nn.ReLU (MedMamba.py:347), applied here;
+ *   ssm_scale (batch) or NULL: per-sample DropPath factor mask/keep_prob of self.drop_path (MedMamba.py:335, 353).
+ * Backward: dleft (batch, C2, P) and dssm (same layout as ssm) from dout (batch, P, 2*C2); d(inp) = dout;
+ *   left_pre = the same pre-activation (ReLU mask) or NULL. */
+int mm_shuffle_residual_fwd(const float* left, const float* ssm, const float* inp, float* out, const float* ssm_scale,
+                            int left_relu, int batch, int P, int C2, int ssm_channel_first, void* stream);
+int mm_shuffle_residual_bwd(const float* dout, float* dleft, float* dssm, const float* ssm_scale, const float* left_pre,
+                            int batch, int P, int C2, int ssm_channel_first, void* stream);
 
 /* ---- SS2D in channel-first planes (everything between in_proj and out_proj is (batch, channel, H*W)) ----------
  * mm_dwconv_silu_cross_fwd: depthwise conv3x3 (pad 1) + bias + SiLU (MedMamba.py:153-162, 295) that writes the scan's
@@ -158,6 +162,17 @@ int mm_block_split_fwd(const float* inp, const float* gamma, const float* beta, 
 int mm_block_split_bwd(const float* dleft_nchw, const float* drn, const float* inp, const float* gamma, const float* mu,
                        const float* rstd, float* dinp, float* ws, int batch, int P, int C2, void* stream);
 int mm_block_split_rows(int batch, int P, int C2);
+
+/* SS2D parameters (MedMamba.py:150-175) -> one buffer in kernel direction order, A = -exp(A_logs) (MedMamba.py:271):
+ *   x_proj_w (4, C, D), dt_w (4, D, R), dt_b (4, D), A_logs (4*D, N), Ds (4*D) in the reference's direction order
+ *   k = (row fwd, col fwd, row rev, col rev);  packed = [Wx 4*C*D | Wdt 4*D*R | A 4*D*N | D 4*D | bias 4*D] floats
+ *   in kernel order g = (row fwd, row rev, col fwd, col rev).  mm_ss2d_pack_size = number of floats.
+ * mm_ss2d_pack_bwd: dpacked (gradient in packed layout) -> grads (same segment layout, reference direction order,
+ *   A segment = gradient w.r.t. A_logs = dA * A). */
+int mm_ss2d_pack_size(int D, int C, int R, int N);
+int mm_ss2d_pack_fwd(const float* x_proj_w, const float* dt_w, const float* dt_b, const float* A_logs, const float* Ds,
+                     float* packed, int D, int C, int R, int N, void* stream);
+int mm_ss2d_pack_bwd(const float* dpacked, const float* packed, float* grads, int D, int C, int R, int N, void* stream);
 
 int mm_abi_version(void);
 const char* mm_status_string(int status);

@@ -39,7 +39,7 @@ SYMBOLS = {
     "mm_status_string": (ctypes.c_char_p, [ctypes.c_int]),
     "mm_scan_fwd": (ctypes.c_int, [ctypes.POINTER(ScanArgs), ctypes.c_void_p]),
     "mm_scan_bwd": (ctypes.c_int, [ctypes.POINTER(ScanArgs), ctypes.c_void_p]),
-    "mm_shuffle_residual_fwd": (ctypes.c_int, [_f32p] * 4 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
+    "mm_shuffle_residual_fwd": (ctypes.c_int, [_f32p] * 5 + [ctypes.c_int] * 5 + [ctypes.c_void_p]),
     "mm_dwconv_silu_cross_fwd": (ctypes.c_int, [_f32p, ctypes.c_int64, _f32p, _f32p, _f32p] + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
     "mm_dwconv_silu_cross_bwd": (ctypes.c_int, [_f32p, _f32p, ctypes.c_int64, _f32p, _f32p, _f32p, ctypes.c_int64, _f32p]
                                  + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
@@ -54,7 +54,10 @@ SYMBOLS = {
                            + [ctypes.c_void_p]),
     "mm_block_split_bwd": (ctypes.c_int, [_f32p] * 8 + [ctypes.c_int] * 3 + [ctypes.c_void_p]),
     "mm_block_split_rows": (ctypes.c_int, [ctypes.c_int] * 3),
-    "mm_shuffle_residual_bwd": (ctypes.c_int, [_f32p] * 3 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
+    "mm_shuffle_residual_bwd": (ctypes.c_int, [_f32p] * 5 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
+    "mm_ss2d_pack_size": (ctypes.c_int, [ctypes.c_int] * 4),
+    "mm_ss2d_pack_fwd": (ctypes.c_int, [_f32p] * 6 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
+    "mm_ss2d_pack_bwd": (ctypes.c_int, [_f32p] * 3 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
 }
 
 _lib = None
@@ -79,7 +82,7 @@ def lib():
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(handle, name)      # AttributeError if the .so is stale
             fn.restype, fn.argtypes = res, args
-        if handle.mm_abi_version() != 4:
+        if handle.mm_abi_version() != 5:
             raise MedMambaHipError("libmedmamba_hip.so ABI version mismatch; rebuild")
         _lib = handle
     return _lib

@@ -16,12 +16,15 @@ using namespace mm;
 template <bool SSM_CF>
 __global__ __launch_bounds__(256) void shuffle_residual_fwd_kernel(const float* __restrict__ left, const float* __restrict__ ssm,
                                                                    const float* __restrict__ inp, float* __restrict__ out,
+                                                                   const float* __restrict__ ssm_scale, int left_relu,
                                                                    int P, int C2) {
   __shared__ float tile[32][33];
   __shared__ float tile2[SSM_CF ? 32 : 1][33];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const int p0 = blockIdx.x * 32, i0 = blockIdx.y * 32, b = blockIdx.z;
   const float* lb = left + (int64_t)b * C2 * P;
+  const float sc = ssm_scale ? ssm_scale[b] : 1.0f;        // DropPath keep-mask / keep_prob of sample b
+  const float lo = left_relu ? 0.0f : -__builtin_inff();   // trailing ReLU of the conv branch
   // load left[i0+r][p0+tx] (lanes along p)
 #pragma unroll
   for (int r = ty; r < 32; r += 8) {
@@ -38,25 +41,29 @@ __global__ __launch_bounds__(256) void shuffle_residual_fwd_kernel(const float* 
     if (p < P && i < C2) {
       const float2 in2 = *reinterpret_cast<const float2*>(inp + ob + (int64_t)p * 2 * C2 + 2 * i);
       const float s = SSM_CF ? tile2[tx][r] : ssm[((int64_t)b * P + p) * C2 + i];
-      *reinterpret_cast<float2*>(out + ob + (int64_t)p * 2 * C2 + 2 * i) = make_float2(tile[tx][r] + in2.x, s + in2.y);
+      *reinterpret_cast<float2*>(out + ob + (int64_t)p * 2 * C2 + 2 * i) =
+          make_float2(fmaxf(tile[tx][r], lo) + in2.x, fmaf(s, sc, in2.y));
     }
   }
 }
 
 template <bool SSM_CF>
 __global__ __launch_bounds__(256) void shuffle_residual_bwd_kernel(const float* __restrict__ dout, float* __restrict__ dleft,
-                                                                   float* __restrict__ dssm, int P, int C2) {
+                                                                   float* __restrict__ dssm, const float* __restrict__ ssm_scale,
+                                                                   const float* __restrict__ left_pre, int P, int C2) {
   __shared__ float tile[32][33];
   __shared__ float tile2[SSM_CF ? 32 : 1][33];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const int p0 = blockIdx.x * 32, i0 = blockIdx.y * 32, b = blockIdx.z;
   const int64_t ob = (int64_t)b * P * (2 * C2);
+  const float sc = ssm_scale ? ssm_scale[b] : 1.0f;
 #pragma unroll
   for (int r = ty; r < 32; r += 8) {
     const int p = p0 + r, i = i0 + tx;
     float2 g = make_float2(0.f, 0.f);
     if (p < P && i < C2) {
       g = *reinterpret_cast<const float2*>(dout + ob + (int64_t)p * 2 * C2 + 2 * i);
+      g.y *= sc;
       if constexpr (!SSM_CF) dssm[((int64_t)b * P + p) * C2 + i] = g.y;
     }
     tile[r][tx] = g.x;       // [p][i]
@@ -64,11 +71,13 @@ __global__ __launch_bounds__(256) void shuffle_residual_bwd_kernel(const float* 
   }
   __syncthreads();
   float* lb = dleft + (int64_t)b * C2 * P;
+  const float* lp = left_pre ? left_pre + (int64_t)b * C2 * P : nullptr;   // ReLU mask from the pre-activation
 #pragma unroll
   for (int r = ty; r < 32; r += 8) {
     const int i = i0 + r, p = p0 + tx;
     if (i < C2 && p < P) {
-      lb[(int64_t)i * P + p] = tile[tx][r];
+      const bool on = lp ? lp[(int64_t)i * P + p] > 0.0f : true;
+      lb[(int64_t)i * P + p] = on ? tile[tx][r] : 0.0f;
       if constexpr (SSM_CF) dssm[((int64_t)b * C2 + i) * P + p] = tile2[tx][r];
     }
   }
@@ -77,25 +86,25 @@ __global__ __launch_bounds__(256) void shuffle_residual_bwd_kernel(const float* 
 
 extern "C" {
 
-int mm_shuffle_residual_fwd(const float* left, const float* ssm, const float* inp, float* out, int batch, int P, int C2,
-                            int ssm_channel_first, void* stream) {
+int mm_shuffle_residual_fwd(const float* left, const float* ssm, const float* inp, float* out, const float* ssm_scale,
+                            int left_relu, int batch, int P, int C2, int ssm_channel_first, void* stream) {
   if (!left || !ssm || !inp || !out) return MM_ERR_NULL;
   if (batch <= 0 || P <= 0 || C2 <= 0 || batch > 65535) return MM_ERR_SHAPE;
   if ((reinterpret_cast<uintptr_t>(inp) | reinterpret_cast<uintptr_t>(out)) & 7) return MM_ERR_ALIGN;
   dim3 grid((P + 31) / 32, (C2 + 31) / 32, batch);
-  if (ssm_channel_first) hipLaunchKernelGGL(shuffle_residual_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, left, ssm, inp, out, P, C2);
-  else hipLaunchKernelGGL(shuffle_residual_fwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, left, ssm, inp, out, P, C2);
+  if (ssm_channel_first) hipLaunchKernelGGL(shuffle_residual_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, left, ssm, inp, out, ssm_scale, left_relu, P, C2);
+  else hipLaunchKernelGGL(shuffle_residual_fwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, left, ssm, inp, out, ssm_scale, left_relu, P, C2);
   return (int)hipGetLastError();
 }
 
-int mm_shuffle_residual_bwd(const float* dout, float* dleft, float* dssm, int batch, int P, int C2, int ssm_channel_first,
-                            void* stream) {
+int mm_shuffle_residual_bwd(const float* dout, float* dleft, float* dssm, const float* ssm_scale, const float* left_pre,
+                            int batch, int P, int C2, int ssm_channel_first, void* stream) {
   if (!dout || !dleft || !dssm) return MM_ERR_NULL;
   if (batch <= 0 || P <= 0 || C2 <= 0 || batch > 65535) return MM_ERR_SHAPE;
   if (reinterpret_cast<uintptr_t>(dout) & 7) return MM_ERR_ALIGN;
   dim3 grid((P + 31) / 32, (C2 + 31) / 32, batch);
-  if (ssm_channel_first) hipLaunchKernelGGL(shuffle_residual_bwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, dout, dleft, dssm, P, C2);
-  else hipLaunchKernelGGL(shuffle_residual_bwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, dout, dleft, dssm, P, C2);
+  if (ssm_channel_first) hipLaunchKernelGGL(shuffle_residual_bwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, dout, dleft, dssm, ssm_scale, left_pre, P, C2);
+  else hipLaunchKernelGGL(shuffle_residual_bwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, dout, dleft, dssm, ssm_scale, left_pre, P, C2);
   return (int)hipGetLastError();
 }
 
@@ -676,6 +685,77 @@ int mm_block_split_bwd(const float* dleft_nchw, const float* drn, const float* i
   hipLaunchKernelGGL(half_transpose_kernel<true>, dim3(((P + 31) / 32) * ((C2 + 31) / 32) * batch), dim3(256), 0, s, dleft_nchw, dinp, P, C, C2);
   if (C2 <= 128) hipLaunchKernelGGL(ln_half_bwd_kernel<16>, dim3(ln_half_grid(nrows, 16)), dim3(256), 0, s, drn, inp, gamma, mu, rstd, dinp, ws, nrows, C, C2);
   else hipLaunchKernelGGL(ln_half_bwd_kernel<64>, dim3(ln_half_grid(nrows, 64)), dim3(256), 0, s, drn, inp, gamma, mu, rstd, dinp, ws, nrows, C, C2);
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"
+
+// =====================================================================================================
+// SS2D parameter packing: the five direction-indexed parameters (reference order k = row fwd, col fwd, row rev,
+// col rev: MedMamba.py:256-257) -> one buffer in KERNEL direction order g = (row fwd, row rev, col fwd, col rev),
+// with A = -exp(A_logs) (MedMamba.py:271).  k(g) = (0,2,1,3) is an involution, so the gradient un-packing is the
+// same index map.  Layout of the packed buffer (floats): [Wx 4*C*D | Wdt 4*D*R | A 4*D*N | D 4*D | bias 4*D].
+// =====================================================================================================
+namespace {
+struct PackSeg { int per_dir[5]; int off[6]; };
+
+__device__ __forceinline__ PackSeg pack_layout(int D, int C, int R, int N) {
+  PackSeg s;
+  s.per_dir[0] = C * D; s.per_dir[1] = D * R; s.per_dir[2] = D * N; s.per_dir[3] = D; s.per_dir[4] = D;
+  s.off[0] = 0;
+#pragma unroll
+  for (int i = 0; i < 5; ++i) s.off[i + 1] = s.off[i] + 4 * s.per_dir[i];
+  return s;
+}
+
+// BWD = false: P[packed] = f(src_seg[k-order]);  BWD = true: G[k-order, same segment layout] = dP[packed] * (A-seg ? P : 1)
+template <bool BWD>
+__global__ __launch_bounds__(256) void ss2d_pack_kernel(const float* __restrict__ s0, const float* __restrict__ s1,
+                                                        const float* __restrict__ s2, const float* __restrict__ s3,
+                                                        const float* __restrict__ s4, float* __restrict__ dst, int D, int C,
+                                                        int R, int N) {
+  const PackSeg L = pack_layout(D, C, R, N);
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= L.off[5]) return;
+  int seg = 0;
+#pragma unroll
+  for (int q = 1; q < 5; ++q) seg += i >= L.off[q];
+  const int local = i - L.off[seg], pd = L.per_dir[seg];
+  const int g = local / pd, rem = local - g * pd;
+  const int k = ((g & 1) << 1) | (g >> 1);
+  const int j = k * pd + rem;           // index inside the segment, reference direction order
+  if constexpr (!BWD) {
+    const float* src = seg == 0 ? s0 : seg == 1 ? s1 : seg == 2 ? s3 : seg == 3 ? s4 : s2;   // (Wx, Wdt, bias, A_logs, Ds)
+    const float v = src[j];
+    dst[i] = seg == 2 ? -expf(v) : v;
+  } else {
+    // s0 = dP (packed), s1 = P (packed): d(A_logs) = dA * A
+    const float v = s0[i] * (seg == 2 ? s1[i] : 1.0f);
+    dst[L.off[seg] + j] = v;
+  }
+}
+}  // namespace
+
+extern "C" {
+
+int mm_ss2d_pack_size(int D, int C, int R, int N) { return 4 * (C * D + D * R + D * N + 2 * D); }
+
+int mm_ss2d_pack_fwd(const float* x_proj_w, const float* dt_w, const float* dt_b, const float* A_logs, const float* Ds,
+                     float* packed, int D, int C, int R, int N, void* stream) {
+  if (!x_proj_w || !dt_w || !dt_b || !A_logs || !Ds || !packed) return MM_ERR_NULL;
+  if (D <= 0 || C <= 0 || R <= 0 || N <= 0) return MM_ERR_SHAPE;
+  const int n = mm_ss2d_pack_size(D, C, R, N);
+  hipLaunchKernelGGL(ss2d_pack_kernel<false>, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, x_proj_w, dt_w, dt_b,
+                     A_logs, Ds, packed, D, C, R, N);
+  return (int)hipGetLastError();
+}
+
+int mm_ss2d_pack_bwd(const float* dpacked, const float* packed, float* grads, int D, int C, int R, int N, void* stream) {
+  if (!dpacked || !packed || !grads) return MM_ERR_NULL;
+  if (D <= 0 || C <= 0 || R <= 0 || N <= 0) return MM_ERR_SHAPE;
+  const int n = mm_ss2d_pack_size(D, C, R, N);
+  hipLaunchKernelGGL(ss2d_pack_kernel<true>, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, dpacked, packed, nullptr,
+                     nullptr, nullptr, grads, D, C, R, N);
   return (int)hipGetLastError();
 }
 

@@ -48,14 +48,19 @@ class DropPath(nn.Module):
         self.drop_prob = drop_prob
         self.scale_by_keep = scale_by_keep
 
-    def forward(self, x):
+    def factor(self, x):
+        """Per-sample factor mask / keep_prob of shape (B, 1, ..., 1) — the same random draw as forward() — or None."""
         if self.drop_prob == 0.0 or not self.training:
-            return x
+            return None
         keep = 1.0 - self.drop_prob
         mask = x.new_empty((x.shape[0],) + (1,) * (x.ndim - 1)).bernoulli_(keep)
         if keep > 0.0 and self.scale_by_keep:
             mask.div_(keep)
-        return x * mask
+        return mask
+
+    def forward(self, x):
+        mask = self.factor(x)
+        return x if mask is None else x * mask
 
     def __repr__(self):
         return f"timm.DropPath({self.drop_prob})"
@@ -231,12 +236,10 @@ class SS2D(nn.Module):
         L, D, R, N = H * W, self.d_inner, self.dt_rank, self.d_state
         x_cf, z_cf = in_proj_cf(x.reshape(B, L, -1), self.in_proj.weight, self.in_proj.bias)  # :291-292, (B, D, L) each
         u2 = dwconv_silu_cross(x_cf, self.conv2d.weight, self.conv2d.bias, H, W)            # :294-295 + :256
-        # kernel direction g = (0,1,2,3) <-> reference direction k = (0,2,1,3): a 2x2 transpose of the leading dim
-        pk = lambda t: t.reshape(2, 2, *t.shape[1:]).transpose(0, 1).reshape(t.shape)
-        y_cf = ss2d_core(u2, pk(self.x_proj_weight), pk(self.dt_projs_weight),               # :259-262 inside
-                         -torch.exp(pk(self.A_logs.float().view(4, D, N))).view(4 * D, N),
-                         pk(self.Ds.float().view(4, D)).reshape(-1), pk(self.dt_projs_bias.float()).reshape(-1),
-                         z_cf, self.out_norm.weight, self.out_norm.bias, H, W, self.out_norm.eps)   # :273-301
+        # projections (:259-262), A = -exp(A_logs) (:271), scan, merge, out_norm and gate (:273-301); the parameters go in
+        # as the module holds them, the kernel-order packing is one launch inside
+        y_cf = ss2d_core(u2, self.x_proj_weight, self.dt_projs_weight, self.dt_projs_bias, self.A_logs, self.Ds,
+                         z_cf, self.out_norm.weight, self.out_norm.bias, H, W, self.out_norm.eps)
         out = torch.bmm(self.out_proj.weight.unsqueeze(0).expand(B, -1, -1), y_cf)           # :302, (B, d_model, L)
         if self.out_proj.bias is not None:
             out = out + self.out_proj.bias[:, None]
@@ -279,6 +282,9 @@ class SS_Conv_SSM(nn.Module):
         else:                                                  # any other norm_layer: the reference's own op chain
             left, right = input.chunk(2, dim=-1)
             left, right_n = left.permute(0, 3, 1, 2).contiguous(), self.ln_1(right)
+        conv = self.conv33conv33conv11
+        fold_relu = isinstance(conv[-1], nn.ReLU)              # the trailing ReLU (:347) is applied by shuffle_residual
+        conv_body = conv[:-1] if fold_relu else conv
         if _TWO_STREAMS and input.is_cuda:
             # the conv branch and the SS2D branch are independent (MedMamba.py:351-353): run the conv branch on a side
             # HIP stream so that its MIOpen kernels overlap the scan (autograd replays the backward on the same streams)
@@ -287,15 +293,17 @@ class SS_Conv_SSM(nn.Module):
             side.wait_stream(main)
             left.record_stream(side)       # allocated on `main`, read by the side stream in forward and backward
             with torch.cuda.stream(side):
-                left = self.conv33conv33conv11(left)                                         # stays NCHW
-            x_cf = self.drop_path(self.self_attention.forward_cf(right_n))                   # (B, C/2, H*W)
+                left = conv_body(left)                                                       # stays NCHW
+            x_cf = self.self_attention.forward_cf(right_n)                                   # (B, C/2, H*W)
             main.wait_stream(side)
             left.record_stream(main)
         else:
-            x_cf = self.drop_path(self.self_attention.forward_cf(right_n))                   # (B, C/2, H*W)
-            left = self.conv33conv33conv11(left)                                             # stays NCHW
-        # permute back + cat + channel_shuffle(groups=2) + residual (MedMamba.py:354-357) fused in one HIP kernel
-        return shuffle_residual(left, x_cf, input, channel_first=True)
+            x_cf = self.self_attention.forward_cf(right_n)                                   # (B, C/2, H*W)
+            left = conv_body(left)                                                           # stays NCHW
+        # trailing ReLU + drop_path + permute back + cat + channel_shuffle(groups=2) + residual (MedMamba.py:347, 353-357)
+        # fused in one HIP kernel
+        return shuffle_residual(left, x_cf, input, channel_first=True, ssm_scale=self.drop_path.factor(x_cf),
+                                left_relu=fold_relu)
 
 
 class VSSLayer(nn.Module):

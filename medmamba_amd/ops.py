@@ -17,37 +17,48 @@ def _need_hip(*ts):
 class ShuffleResidualFn(torch.autograd.Function):
     """out = channel_shuffle(cat(left_nhwc, ssm), 2) + inp   (MedMamba.py:354-357) in one kernel.
     left: (B, C/2, H, W) NCHW conv-branch output; ssm: SS2D-branch output, (B, H, W, C/2) or — channel_first —
-    (B, C/2, H*W); inp: (B, H, W, C)."""
+    (B, C/2, H*W); inp: (B, H, W, C).  Optionally folds in the two neighbours of the chain: left_relu — `left` is the
+    pre-activation of the conv branch's trailing ReLU (MedMamba.py:347); ssm_scale (B,) — the DropPath factor
+    mask / keep_prob of every sample (MedMamba.py:335, 353)."""
 
     @staticmethod
-    def forward(ctx, left, ssm, inp, channel_first):
+    def forward(ctx, left, ssm, inp, channel_first, ssm_scale, left_relu):
         left, ssm, inp = left.float().contiguous(), ssm.float().contiguous(), inp.float().contiguous()
         B, C2, H, W = left.shape
+        if ssm_scale is not None:
+            ssm_scale = ssm_scale.float().contiguous()
+            assert ssm_scale.numel() == B
         out = torch.empty_like(inp)
         with torch.cuda.device(inp.device):
             rc = _lib.lib().mm_shuffle_residual_fwd(left.data_ptr(), ssm.data_ptr(), inp.data_ptr(), out.data_ptr(),
+                                                    None if ssm_scale is None else ssm_scale.data_ptr(), int(bool(left_relu)),
                                                     B, H * W, C2, int(channel_first), _stream())
         _lib.check(rc, "mm_shuffle_residual_fwd")
         ctx.shape = (B, C2, H, W)
         ctx.cf = bool(channel_first)
+        ctx.relu = bool(left_relu)
+        ctx.save_for_backward(ssm_scale, left if left_relu else None)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         B, C2, H, W = ctx.shape
+        ssm_scale, left_pre = ctx.saved_tensors
         dout = dout.float().contiguous()
         dleft = torch.empty((B, C2, H, W), device=dout.device, dtype=torch.float32)
         dssm = torch.empty((B, C2, H * W) if ctx.cf else (B, H, W, C2), device=dout.device, dtype=torch.float32)
         with torch.cuda.device(dout.device):
-            rc = _lib.lib().mm_shuffle_residual_bwd(dout.data_ptr(), dleft.data_ptr(), dssm.data_ptr(), B, H * W, C2,
-                                                    int(ctx.cf), _stream())
+            rc = _lib.lib().mm_shuffle_residual_bwd(dout.data_ptr(), dleft.data_ptr(), dssm.data_ptr(),
+                                                    None if ssm_scale is None else ssm_scale.data_ptr(),
+                                                    None if left_pre is None else left_pre.data_ptr(),
+                                                    B, H * W, C2, int(ctx.cf), _stream())
         _lib.check(rc, "mm_shuffle_residual_bwd")
-        return dleft, dssm, dout, None
+        return dleft, dssm, dout, None, None, None
 
 
-def shuffle_residual(left_nchw, ssm, inp_nhwc, channel_first=False):
+def shuffle_residual(left_nchw, ssm, inp_nhwc, channel_first=False, ssm_scale=None, left_relu=False):
     _need_hip(left_nchw, ssm, inp_nhwc)
-    return ShuffleResidualFn.apply(left_nchw, ssm, inp_nhwc, channel_first)
+    return ShuffleResidualFn.apply(left_nchw, ssm, inp_nhwc, channel_first, ssm_scale, left_relu)
 
 
 class InProjFn(torch.autograd.Function):
@@ -137,27 +148,45 @@ def dwconv_silu_cross(x_cf, weight, bias, H, W):
 
 class SS2DCoreFn(torch.autograd.Function):
     """x/dt projections + 4-direction selective scan + cross-merge + out_norm LayerNorm + SiLU(z) gate in channel-first
-    planes (MedMamba.py:259-262, 273-286, 298-301).
+    planes (MedMamba.py:259-262, 271-286, 298-301).
 
-    u2 (B, 2D, L): row-major | column-major image (dwconv_silu_cross);  Wx (4, R+2N, D), Wdt (4, D, R), A (4D, N),
-    Dp, dbias (4D) — all in KERNEL direction order (row-major fwd/rev, column-major fwd/rev);  z_cf (B, D, L);
-    LayerNorm weight / bias / eps; image size.  Returns y_cf (B, D, L) = LN_D(merge(scan(...))) * silu(z).
+    u2 (B, 2D, L): row-major | column-major image (dwconv_silu_cross);  the five SS2D parameters exactly as the module
+    holds them (reference direction order): x_proj_weight (4, R+2N, D), dt_projs_weight (4, D, R), dt_projs_bias (4, D),
+    A_logs (4D, N), Ds (4D);  z_cf (B, D, L);  LayerNorm weight / bias / eps; image size.
+    Returns y_cf (B, D, L) = LN_D(merge(scan(...))) * silu(z).
 
-    The projections live inside the Function so that autograd never slices x_dbl: the backward kernel writes dB / dC
-    straight into the row blocks of d(x_dbl) (strided outputs of mm_scan_bwd), the dt rows are filled by one GEMM, and
-    d(u2) collects its three contributions (two direction pairs + the x projection) with one add and one GEMM
-    (beta = 1).  Saved: u2, x_dbl, delta, the state checkpoints, the merged pre-norm tensor m and the LN statistics;
-    the (B, 4D, L) scan output is freed after the merge."""
+    One kernel (mm_ss2d_pack_fwd) brings the parameters into kernel direction order with A = -exp(A_logs); its mirror
+    returns all five parameter gradients from one packed buffer that the GEMMs and the backward scan write into — no
+    per-parameter permute / exp / zero-fill launches.  The projections live inside the Function so that autograd
+    never slices x_dbl: the backward kernel writes dB / dC straight into the row blocks of d(x_dbl) (strided outputs of
+    mm_scan_bwd), the dt rows are filled by one GEMM, and d(u2) collects its three contributions (two direction pairs
+    + the x projection) with one add and one GEMM (beta = 1).  Saved: u2, x_dbl, delta, the packed parameters, the
+    state checkpoints, the merged pre-norm tensor m and the LN statistics; the (B, 4D, L) scan output is freed after
+    the merge."""
 
     @staticmethod
-    def forward(ctx, u2, Wx, Wdt, A, Dp, dbias, z_cf, ln_w, ln_b, H, W, eps):
+    def _segments(P, D, C, R, N):
+        o1 = 4 * C * D
+        o2 = o1 + 4 * D * R
+        o3 = o2 + 4 * D * N
+        o4 = o3 + 4 * D
+        return (P[:o1].view(4, C, D), P[o1:o2].view(4, D, R), P[o2:o3].view(4 * D, N), P[o3:o4], P[o4:])
+
+    @staticmethod
+    def forward(ctx, u2, x_proj_w, dt_w, dt_b, A_logs, Ds, z_cf, ln_w, ln_b, H, W, eps):
         from .selective_scan_interface import _CROSS_SHARED, _launch_fwd
         Bsz, D2, L = u2.shape
-        D, R, N = D2 // 2, Wdt.shape[2], A.shape[1]
+        D, R, N = D2 // 2, dt_w.shape[2], A_logs.shape[1]
         C = R + 2 * N
+        dev = u2.device
+        lib = _lib.lib()
         u2 = u2.float().contiguous()
-        Wx, Wdt, A = Wx.float().contiguous(), Wdt.float().contiguous(), A.float().contiguous()
-        Dp, dbias = Dp.float().contiguous(), dbias.float().contiguous()
+        srcs = [t.float().contiguous() for t in (x_proj_w, dt_w, dt_b, A_logs, Ds)]
+        P = torch.empty((lib.mm_ss2d_pack_size(D, C, R, N),), device=dev, dtype=torch.float32)
+        with torch.cuda.device(dev):
+            rc = lib.mm_ss2d_pack_fwd(*[t.data_ptr() for t in srcs], P.data_ptr(), D, C, R, N, _stream())
+        _lib.check(rc, "mm_ss2d_pack_fwd")
+        Wx, Wdt, A, Dp, dbias = SS2DCoreFn._segments(P, D, C, R, N)
         x_dbl = torch.matmul(Wx.view(1, 2, 2 * C, D), u2.view(Bsz, 2, D, L)).view(Bsz, 4, C, L)        # :259
         delta = torch.matmul(Wdt.unsqueeze(0), x_dbl[:, :, :R]).view(Bsz, 4 * D, L)                    # :262
         need_grad = any(ctx.needs_input_grad)
@@ -167,12 +196,10 @@ class SS2DCoreFn(torch.autograd.Function):
         if z_cf.stride(2) != 1 or z_cf.stride(1) != L:
             z_cf = z_cf.contiguous()
         ln_w, ln_b = ln_w.float().contiguous(), ln_b.float().contiguous()
-        dev = u2.device
         m = torch.empty((Bsz, D, L), device=dev, dtype=torch.float32)
         y = torch.empty((Bsz, D, L), device=dev, dtype=torch.float32)
         mu = torch.empty((Bsz, L), device=dev, dtype=torch.float32)
         rstd = torch.empty((Bsz, L), device=dev, dtype=torch.float32)
-        lib = _lib.lib()
         with torch.cuda.device(dev):
             rc = lib.mm_cross_merge_fwd(out4.data_ptr(), m.data_ptr(), Bsz, D, H, W, _stream())
             _lib.check(rc, "mm_cross_merge_fwd")
@@ -180,18 +207,17 @@ class SS2DCoreFn(torch.autograd.Function):
                                     y.data_ptr(), mu.data_ptr(), rstd.data_ptr(), Bsz, D, L, _stream())
             _lib.check(rc, "mm_ln_gate_fwd")
         if need_grad:
-            ctx.save_for_backward(u2, x_dbl, delta, Wx, Wdt, A, Dp, dbias, x_chk, m, mu, rstd, z_cf, ln_w, ln_b)
-            ctx.hw = (H, W)
+            ctx.save_for_backward(u2, x_dbl, delta, P, x_chk, m, mu, rstd, z_cf, ln_w, ln_b)
+            ctx.dims = (H, W, D, C, R, N)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         from .selective_scan_interface import _CROSS_SHARED, _launch_bwd
-        u2, x_dbl, delta, Wx, Wdt, A, Dp, dbias, x_chk, m, mu, rstd, z_cf, ln_w, ln_b = ctx.saved_tensors
-        H, W = ctx.hw
-        Bsz, D, L = m.shape
-        R, N = Wdt.shape[2], A.shape[1]
-        C = R + 2 * N
+        u2, x_dbl, delta, P, x_chk, m, mu, rstd, z_cf, ln_w, ln_b = ctx.saved_tensors
+        H, W, D, C, R, N = ctx.dims
+        Wx, Wdt, A, Dp, dbias = SS2DCoreFn._segments(P, D, C, R, N)
+        Bsz, _, L = m.shape
         dev = m.device
         dy = dy.float().contiguous()
         dout2 = torch.empty((Bsz, 2 * D, L), device=dev, dtype=torch.float32)    # block 0: dm, block 1: its plane transpose
@@ -207,13 +233,16 @@ class SS2DCoreFn(torch.autograd.Function):
                                         Bsz, D, H, W, _stream())
             _lib.check(rc, "mm_plane_transpose")
         wsum = ws.sum(0)
+        # gradient of the packed parameters: the A / D / bias segments are accumulated with atomics -> one zero-fill
+        dP = torch.empty_like(P)
+        dWx, dWdt, dA, dD, ddb = SS2DCoreFn._segments(dP, D, C, R, N)
+        dP[4 * C * D + 4 * D * R:].zero_()
         dx_dbl = torch.zeros((Bsz, 4, C, L), device=dev, dtype=torch.float32)    # dB/dC are accumulated (atomics for D > 128)
-        du4, ddelta, dA, _, _, dD, ddb = _launch_bwd(u2, delta, A, x_dbl[:, :, R:R + N], x_dbl[:, :, R + N:], Dp, dbias, x_chk,
-                                                    dout2, True, _CROSS_SHARED,
-                                                    dBC=(dx_dbl[:, :, R:R + N], dx_dbl[:, :, R + N:]))
+        du4, ddelta = _launch_bwd(u2, delta, A, x_dbl[:, :, R:R + N], x_dbl[:, :, R + N:], Dp, dbias, x_chk, dout2, True,
+                                  _CROSS_SHARED, dBC=(dx_dbl[:, :, R:R + N], dx_dbl[:, :, R + N:]), dparams=(dA, dD, ddb))[:2]
         dd = ddelta.view(Bsz, 4, D, L)
         xr = x_dbl[:, :, :R]
-        dWdt = torch.matmul(dd, xr.transpose(-1, -2)).sum(0)                                  # (4, D, R)
+        torch.sum(torch.matmul(dd, xr.transpose(-1, -2)), 0, out=dWdt)                       # (4, D, R)
         dx_dbl[:, :, :R] = torch.matmul(Wdt.transpose(-1, -2).unsqueeze(0), dd)               # dt rows of d(x_dbl)
         d4 = du4.view(Bsz, 2, 2, D, L)
         du2 = (d4[:, :, 0] + d4[:, :, 1]).view(Bsz * 2, D, L)                                 # the two directions of a pair
@@ -221,16 +250,24 @@ class SS2DCoreFn(torch.autograd.Function):
         dxd2 = dx_dbl.view(Bsz, 2, 2 * C, L)
         du2.baddbmm_(Wx2.transpose(1, 2).unsqueeze(0).expand(Bsz, -1, -1, -1).reshape(Bsz * 2, D, 2 * C),
                      dxd2.reshape(Bsz * 2, 2 * C, L))                                       # + Wx^T d(x_dbl)
-        dWx = torch.matmul(dxd2, u2.view(Bsz, 2, D, L).transpose(-1, -2)).sum(0).view(4, C, D)
-        return (du2.view(Bsz, 2 * D, L), dWx, dWdt, dA, dD, ddb, dz, wsum[:D].contiguous(), wsum[D:].contiguous(),
-                None, None, None)
+        torch.sum(torch.matmul(dxd2, u2.view(Bsz, 2, D, L).transpose(-1, -2)), 0, out=dWx.view(2, 2 * C, D))
+        G = torch.empty_like(P)
+        with torch.cuda.device(dev):
+            rc = lib.mm_ss2d_pack_bwd(dP.data_ptr(), P.data_ptr(), G.data_ptr(), D, C, R, N, _stream())
+        _lib.check(rc, "mm_ss2d_pack_bwd")
+        gWx, gWdt, gA, gD, gb = SS2DCoreFn._segments(G, D, C, R, N)
+        return (du2.view(Bsz, 2 * D, L), gWx, gWdt, gb.view(4, D), gA, gD, dz, wsum[:D], wsum[D:], None, None, None)
 
 
-def ss2d_core(u2, Wx, Wdt, A, Dp, dbias, z_cf, ln_w, ln_b, H, W, eps=1e-5):
+def ss2d_core(u2, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds, z_cf, ln_w, ln_b, H, W, eps=1e-5):
+    """Parameters in the module's own (reference) layout and direction order; see SS2DCoreFn."""
     _need_hip(u2, z_cf)
-    if A.shape[1] != 16 or Wx.shape[0] != 4 or Wdt.shape[0] != 4 or A.shape[0] != 2 * u2.shape[1]:
+    D = u2.shape[1] // 2
+    if (A_logs.shape != (4 * D, 16) or x_proj_weight.shape[0] != 4 or x_proj_weight.shape[2] != D
+            or dt_projs_weight.shape[:2] != (4, D) or dt_projs_bias.shape != (4, D) or Ds.shape != (4 * D,)
+            or x_proj_weight.shape[1] != dt_projs_weight.shape[2] + 32):
         raise NotImplementedError("ss2d_core: expects 4 directions, d_state 16, u2 with 2*D channels")
-    return SS2DCoreFn.apply(u2, Wx, Wdt, A, Dp, dbias, z_cf, ln_w, ln_b, H, W, eps)
+    return SS2DCoreFn.apply(u2, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds, z_cf, ln_w, ln_b, H, W, eps)
 
 
 class BlockSplitFn(torch.autograd.Function):

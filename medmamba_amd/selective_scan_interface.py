@@ -130,24 +130,28 @@ def _launch_fwd(u, delta, A, B, C, D, delta_bias, delta_softplus, want_chk, vari
     return out, x_chk
 
 
-def _launch_bwd(u, delta, A, B, C, D, delta_bias, x_chk, dout, delta_softplus, shared=(0, 0, 0), dBC=None):
+def _launch_bwd(u, delta, A, B, C, D, delta_bias, x_chk, dout, delta_softplus, shared=(0, 0, 0), dBC=None, dparams=None):
     """mm_scan_bwd on torch's current stream. Returns du (per group), ddelta, dA, dB, dC, dD, dbias.
     dBC: optional (dB_view, dC_view) — zero-filled (batch, G, N, L) views (unit stride along L) to accumulate into,
-    e.g. row blocks of the gradient of x_dbl."""
+    e.g. row blocks of the gradient of x_dbl.  dparams: optional zero-filled (dA (dim, N), dD (dim), dbias (dim))."""
     batch, dim, L = delta.shape
     G, N = B.shape[1], A.shape[1]
     dev = u.device
     du, ddelta = torch.empty_like(delta), torch.empty_like(delta)
     # accumulated with atomics across batch / channel tiles -> zero-filled here (header contract)
-    dA = torch.zeros((dim, N), device=dev, dtype=torch.float32)
+    if dparams is None:
+        dA = torch.zeros((dim, N), device=dev, dtype=torch.float32)
+        dD = None if D is None else torch.zeros((dim,), device=dev, dtype=torch.float32)
+        dbias = None if delta_bias is None else torch.zeros((dim,), device=dev, dtype=torch.float32)
+    else:
+        dA, dD, dbias = dparams
+        assert dA.shape == (dim, N) and dA.is_contiguous() and dD.shape == (dim,) and dbias.shape == (dim,)
     if dBC is None:
         dB = torch.zeros((batch, G, N, L), device=dev, dtype=torch.float32)
         dC = torch.zeros((batch, G, N, L), device=dev, dtype=torch.float32)
     else:
         dB, dC = dBC
         assert dB.stride(3) == 1 and dC.stride(3) == 1 and dB.shape == (batch, G, N, L) == dC.shape
-    dD = None if D is None else torch.zeros((dim,), device=dev, dtype=torch.float32)
-    dbias = None if delta_bias is None else torch.zeros((dim,), device=dev, dtype=torch.float32)
     a = _lib.ScanArgs()
     _fill_common(a, u, delta, A, B, C, D, delta_bias, delta_softplus)
     a.x_chk, a.dout = x_chk.data_ptr(), dout.data_ptr()

@@ -152,12 +152,17 @@ def dt_rank(dim):
     return math.ceil((dim // 2) / 16)
 
 
-def shuffle_residual_ref(left_nchw, ssm, inp_nhwc, channel_first=False):
-    """Test double for medmamba_amd.ops.shuffle_residual: the reference's own op chain, MedMamba.py:354-357.
+def shuffle_residual_ref(left_nchw, ssm, inp_nhwc, channel_first=False, ssm_scale=None, left_relu=False):
+    """Test double for medmamba_amd.ops.shuffle_residual: the reference's own op chain, MedMamba.py:354-357 (with the
+    trailing ReLU of the conv branch, :347, and the DropPath factor of :353 when they are handed over).
     channel_first: ssm is (B, C/2, H*W) instead of (B, H, W, C/2)."""
+    if left_relu:
+        left_nchw = F.relu(left_nchw)
     left = left_nchw.permute(0, 2, 3, 1).contiguous()
     if channel_first:
         ssm = ssm.transpose(1, 2).reshape(left.shape)
+    if ssm_scale is not None:
+        ssm = ssm * ssm_scale.reshape(-1, 1, 1, 1)
     return channel_shuffle(torch.cat((left, ssm), dim=-1), 2) + inp_nhwc
 
 
@@ -175,13 +180,17 @@ def dwconv_silu_cross_ref(x_cf, weight, bias, H, W):
     return torch.stack([xc.reshape(B, D, L), xc.transpose(2, 3).reshape(B, D, L)], 1).reshape(B, 2 * D, L)
 
 
-def ss2d_core_ref(u2, Wx, Wdt, A, Dp, dbias, z_cf, ln_w, ln_b, H, W, eps=1e-5):
-    """Test double for medmamba_amd.ops.ss2d_core: the x / dt projections (MedMamba.py:259-262) as einsums, the oracle scan
-    on explicitly flipped tensors, the reference's merge (:282-286, 298), out_norm (:300) and gate (:301), channel-first.
-    Weights are given in kernel direction order (row-major fwd/rev, column-major fwd/rev)."""
+def ss2d_core_ref(u2, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds, z_cf, ln_w, ln_b, H, W, eps=1e-5):
+    """Test double for medmamba_amd.ops.ss2d_core: the x / dt projections (MedMamba.py:259-262) as einsums, A = -exp(A_logs)
+    (:271), the oracle scan on explicitly flipped tensors, the reference's merge (:282-286, 298), out_norm (:300) and gate
+    (:301), channel-first.  Parameters in the module's (reference) direction order k; the scan double wants kernel order g."""
     from .scan_ref import c_cross_scan_fn
     B, D2, L = u2.shape
-    D, R, N = D2 // 2, Wdt.shape[2], A.shape[1]
+    D, R, N = D2 // 2, dt_projs_weight.shape[2], A_logs.shape[1]
+    pk = lambda t: torch.stack([t[k] for k in (0, 2, 1, 3)], 0)      # kernel direction g -> reference direction k
+    Wx, Wdt = pk(x_proj_weight), pk(dt_projs_weight)
+    A = -torch.exp(pk(A_logs.float().view(4, D, N))).reshape(4 * D, N)
+    Dp, dbias = pk(Ds.float().view(4, D)).reshape(-1), pk(dt_projs_bias.float()).reshape(-1)
     u4 = u2.view(B, 2, 1, D, L).expand(B, 2, 2, D, L).reshape(B, 4, D, L)           # direction g reads block g // 2
     x_dbl = torch.einsum("bgdl,gcd->bgcl", u4, Wx)
     delta = torch.einsum("bgrl,gdr->bgdl", x_dbl[:, :, :R], Wdt).reshape(B, 4 * D, L)

@@ -35,6 +35,20 @@ def test_shuffle_residual_forward_backward(shape):
     assert torch.equal(out_cf.detach().cpu(), ref.detach())
     assert torch.equal(dev_cf[1].grad.cpu(), ref_in[1].grad.reshape(B, H * W, C2).transpose(1, 2))
     assert torch.equal(dev_cf[0].grad.cpu(), ref_in[0].grad)
+    # folded neighbours: trailing ReLU of the conv branch + per-sample DropPath factor (MedMamba.py:347, 353)
+    scale = (torch.rand(B, generator=g) > 0.4).float() / 0.6
+    for cf in (False, True):
+        ref_in = [t.clone().requires_grad_() for t in (left, ssm, inp)]
+        ref = shuffle_residual_ref(*ref_in, ssm_scale=scale, left_relu=True)
+        ref.backward(dout)
+        dev_in = [left.to(DEV).requires_grad_(), (ssm_cf if cf else ssm).to(DEV).requires_grad_(), inp.to(DEV).requires_grad_()]
+        out = shuffle_residual(*dev_in, channel_first=cf, ssm_scale=scale.to(DEV), left_relu=True)
+        out.backward(dout.to(DEV))
+        assert (out.detach().cpu() - ref.detach()).abs().max().item() <= 1e-6      # fma(s, scale, inp) vs mul + add
+        gs = ref_in[1].grad.reshape(B, H * W, C2).transpose(1, 2) if cf else ref_in[1].grad
+        assert torch.equal(dev_in[1].grad.cpu(), gs)
+        assert torch.equal(dev_in[0].grad.cpu(), ref_in[0].grad)
+        assert torch.equal(dev_in[2].grad.cpu(), ref_in[2].grad)
 
 
 def test_in_proj_cf_forward_backward():
@@ -92,11 +106,11 @@ def test_ss2d_core_forward_backward(shape):
     mk = lambda *s: torch.randn(*s, generator=g)
     u2 = mk(B, 2 * D, L)
     Wx, Wdt = mk(4, R + 2 * N, D) / D ** 0.5, mk(4, D, R) / R ** 0.5
-    A = -torch.exp(mk(4 * D, N) * 0.5)
-    Dp, dbias = mk(4 * D), mk(4 * D) - 3
+    A_logs = mk(4 * D, N) * 0.5
+    Dp, dbias = mk(4 * D), mk(4, D) - 3
     z, lw, lb = mk(B, D, L), 1 + 0.1 * mk(D), 0.1 * mk(D)
     dy = mk(B, D, L)
-    leaves = (u2, Wx, Wdt, A, Dp, dbias, z, lw, lb)
+    leaves = (u2, Wx, Wdt, dbias, A_logs, Dp, z, lw, lb)       # parameters in the module's layout / direction order
     ref_in = [t.clone().requires_grad_() for t in leaves]
     ref = ss2d_core_ref(*ref_in, H, W, 1e-5)
     ref.backward(dy)
@@ -105,7 +119,7 @@ def test_ss2d_core_forward_backward(shape):
     out.backward(dy.to(DEV))
     err = (out.detach().cpu() - ref.detach()).abs().max().item()
     assert err <= 5e-5 * max(1.0, ref.detach().abs().max().item()), err
-    names = ["du2", "dWx", "dWdt", "dA", "dD", "dbias", "dz", "dln_w", "dln_b"]
+    names = ["du2", "dWx", "dWdt", "dbias", "dA_logs", "dD", "dz", "dln_w", "dln_b"]
     for n, a, b in zip(names, dev_in, ref_in):
         e = (a.grad.cpu() - b.grad).abs().max().item() / max(1.0, b.grad.abs().max().item())
         assert e <= 5e-4, (n, e)
