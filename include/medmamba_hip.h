@@ -166,7 +166,8 @@ int mm_block_split_rows(int batch, int P, int C2);
 /* SS2D parameters (MedMamba.py:150-175) -> one buffer in kernel direction order, A = -exp(A_logs) (MedMamba.py:271):
  *   x_proj_w (4, C, D), dt_w (4, D, R), dt_b (4, D), A_logs (4*D, N), Ds (4*D) in the reference's direction order
  *   k = (row fwd, col fwd, row rev, col rev);  packed = [Wx 4*C*D | Wdt 4*D*R | A 4*D*N | D 4*D | bias 4*D] floats
- *   in kernel order g = (row fwd, row rev, col fwd, col rev).  mm_ss2d_pack_size = number of floats.
+ *   in kernel order g = (row fwd, row rev, col fwd, col rev); every segment starts on a multiple of 64 floats (256 B)
+ *   and mm_ss2d_pack_size = total number of floats including that padding.
  * mm_ss2d_pack_bwd: dpacked (gradient in packed layout) -> grads (same segment layout, reference direction order,
  *   A segment = gradient w.r.t. A_logs = dA * A). */
 int mm_ss2d_pack_size(int D, int C, int R, int N);

@@ -6,6 +6,8 @@ caller gets an exception.  PyTorch is only the owner of device memory and stream
 import ctypes
 import os
 
+import torch
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "lib", "libmedmamba_hip.so")
 
@@ -96,3 +98,28 @@ def check(rc, what):
 
 def scan_chunk():
     return lib().mm_scan_chunk()
+
+
+class device_guard:
+    """`with torch.cuda.device(dev)` without its Python overhead: switches the current HIP device only when `dev` is not
+    already current (the launch wrappers run once per kernel, ~1400 times per training step)."""
+    __slots__ = ("idx", "prev")
+
+    def __init__(self, device):
+        self.idx = device.index if device.index is not None else torch._C._cuda_getDevice()
+
+    def __enter__(self):
+        self.prev = torch._C._cuda_getDevice()
+        if self.prev != self.idx:
+            torch._C._cuda_setDevice(self.idx)
+        return self
+
+    def __exit__(self, *exc):
+        if self.prev != self.idx:
+            torch._C._cuda_setDevice(self.prev)
+        return False
+
+
+def raw_stream():
+    """hipStream_t of torch's current stream on the current device (the stream every kernel of this library is launched on)."""
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())

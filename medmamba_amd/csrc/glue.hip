@@ -694,17 +694,18 @@ int mm_block_split_bwd(const float* dleft_nchw, const float* drn, const float* i
 // SS2D parameter packing: the five direction-indexed parameters (reference order k = row fwd, col fwd, row rev,
 // col rev: MedMamba.py:256-257) -> one buffer in KERNEL direction order g = (row fwd, row rev, col fwd, col rev),
 // with A = -exp(A_logs) (MedMamba.py:271).  k(g) = (0,2,1,3) is an involution, so the gradient un-packing is the
-// same index map.  Layout of the packed buffer (floats): [Wx 4*C*D | Wdt 4*D*R | A 4*D*N | D 4*D | bias 4*D].
+// same index map.  Layout of the packed buffer (floats): [Wx 4*C*D | Wdt 4*D*R | A 4*D*N | D 4*D | bias 4*D], every
+// segment padded to a multiple of 64 floats (the GEMM libraries pick slower kernels for operands off 256-B alignment).
 // =====================================================================================================
 namespace {
 struct PackSeg { int per_dir[5]; int off[6]; };
 
-__device__ __forceinline__ PackSeg pack_layout(int D, int C, int R, int N) {
+__host__ __device__ __forceinline__ PackSeg pack_layout(int D, int C, int R, int N) {
   PackSeg s;
   s.per_dir[0] = C * D; s.per_dir[1] = D * R; s.per_dir[2] = D * N; s.per_dir[3] = D; s.per_dir[4] = D;
   s.off[0] = 0;
 #pragma unroll
-  for (int i = 0; i < 5; ++i) s.off[i + 1] = s.off[i] + 4 * s.per_dir[i];
+  for (int i = 0; i < 5; ++i) s.off[i + 1] = (s.off[i] + 4 * s.per_dir[i] + 63) & ~63;   // 256-B aligned segments
   return s;
 }
 
@@ -721,6 +722,7 @@ __global__ __launch_bounds__(256) void ss2d_pack_kernel(const float* __restrict_
 #pragma unroll
   for (int q = 1; q < 5; ++q) seg += i >= L.off[q];
   const int local = i - L.off[seg], pd = L.per_dir[seg];
+  if (local >= 4 * pd) return;          // alignment padding between segments
   const int g = local / pd, rem = local - g * pd;
   const int k = ((g & 1) << 1) | (g >> 1);
   const int j = k * pd + rem;           // index inside the segment, reference direction order
@@ -738,7 +740,7 @@ __global__ __launch_bounds__(256) void ss2d_pack_kernel(const float* __restrict_
 
 extern "C" {
 
-int mm_ss2d_pack_size(int D, int C, int R, int N) { return 4 * (C * D + D * R + D * N + 2 * D); }
+int mm_ss2d_pack_size(int D, int C, int R, int N) { return pack_layout(D, C, R, N).off[5]; }
 
 int mm_ss2d_pack_fwd(const float* x_proj_w, const float* dt_w, const float* dt_b, const float* A_logs, const float* Ds,
                      float* packed, int D, int C, int R, int N, void* stream) {

@@ -5,7 +5,7 @@ from . import _lib
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    return _lib.raw_stream()
 
 
 def _need_hip(*ts):
@@ -29,7 +29,7 @@ class ShuffleResidualFn(torch.autograd.Function):
             ssm_scale = ssm_scale.float().contiguous()
             assert ssm_scale.numel() == B
         out = torch.empty_like(inp)
-        with torch.cuda.device(inp.device):
+        with _lib.device_guard(inp.device):
             rc = _lib.lib().mm_shuffle_residual_fwd(left.data_ptr(), ssm.data_ptr(), inp.data_ptr(), out.data_ptr(),
                                                     None if ssm_scale is None else ssm_scale.data_ptr(), int(bool(left_relu)),
                                                     B, H * W, C2, int(channel_first), _stream())
@@ -47,7 +47,7 @@ class ShuffleResidualFn(torch.autograd.Function):
         dout = dout.float().contiguous()
         dleft = torch.empty((B, C2, H, W), device=dout.device, dtype=torch.float32)
         dssm = torch.empty((B, C2, H * W) if ctx.cf else (B, H, W, C2), device=dout.device, dtype=torch.float32)
-        with torch.cuda.device(dout.device):
+        with _lib.device_guard(dout.device):
             rc = _lib.lib().mm_shuffle_residual_bwd(dout.data_ptr(), dleft.data_ptr(), dssm.data_ptr(),
                                                     None if ssm_scale is None else ssm_scale.data_ptr(),
                                                     None if left_pre is None else left_pre.data_ptr(),
@@ -115,7 +115,7 @@ class DwConvSiluCrossFn(torch.autograd.Function):
         weight = weight.float().contiguous()
         bias = None if bias is None else bias.float().contiguous()
         u2 = torch.empty((B, 2 * D, L), device=x_cf.device, dtype=torch.float32)
-        with torch.cuda.device(x_cf.device):
+        with _lib.device_guard(x_cf.device):
             rc = _lib.lib().mm_dwconv_silu_cross_fwd(x_cf.data_ptr(), x_cf.stride(0), weight.data_ptr(),
                                                      None if bias is None else bias.data_ptr(), u2.data_ptr(),
                                                      B, D, H, W, _stream())
@@ -132,7 +132,7 @@ class DwConvSiluCrossFn(torch.autograd.Function):
         du2 = du2.float().contiguous()
         dx = torch.empty((B, D, L), device=du2.device, dtype=torch.float32)
         ws = torch.empty((B, D, 10), device=du2.device, dtype=torch.float32)
-        with torch.cuda.device(du2.device):
+        with _lib.device_guard(du2.device):
             rc = _lib.lib().mm_dwconv_silu_cross_bwd(du2.data_ptr(), x_cf.data_ptr(), x_cf.stride(0), weight.data_ptr(),
                                                      None if bias is None else bias.data_ptr(), dx.data_ptr(), dx.stride(0),
                                                      ws.data_ptr(), B, D, H, W, _stream())
@@ -166,11 +166,13 @@ class SS2DCoreFn(torch.autograd.Function):
 
     @staticmethod
     def _segments(P, D, C, R, N):
-        o1 = 4 * C * D
-        o2 = o1 + 4 * D * R
-        o3 = o2 + 4 * D * N
-        o4 = o3 + 4 * D
-        return (P[:o1].view(4, C, D), P[o1:o2].view(4, D, R), P[o2:o3].view(4 * D, N), P[o3:o4], P[o4:])
+        al = lambda n: (n + 63) & ~63                 # segments start on 256-B boundaries (mm_ss2d_pack_fwd)
+        o1 = al(4 * C * D)
+        o2 = al(o1 + 4 * D * R)
+        o3 = al(o2 + 4 * D * N)
+        o4 = al(o3 + 4 * D)
+        return (P[:4 * C * D].view(4, C, D), P[o1:o1 + 4 * D * R].view(4, D, R), P[o2:o2 + 4 * D * N].view(4 * D, N),
+                P[o3:o3 + 4 * D], P[o4:o4 + 4 * D])
 
     @staticmethod
     def forward(ctx, u2, x_proj_w, dt_w, dt_b, A_logs, Ds, z_cf, ln_w, ln_b, H, W, eps):
@@ -183,7 +185,7 @@ class SS2DCoreFn(torch.autograd.Function):
         u2 = u2.float().contiguous()
         srcs = [t.float().contiguous() for t in (x_proj_w, dt_w, dt_b, A_logs, Ds)]
         P = torch.empty((lib.mm_ss2d_pack_size(D, C, R, N),), device=dev, dtype=torch.float32)
-        with torch.cuda.device(dev):
+        with _lib.device_guard(dev):
             rc = lib.mm_ss2d_pack_fwd(*[t.data_ptr() for t in srcs], P.data_ptr(), D, C, R, N, _stream())
         _lib.check(rc, "mm_ss2d_pack_fwd")
         Wx, Wdt, A, Dp, dbias = SS2DCoreFn._segments(P, D, C, R, N)
@@ -200,7 +202,7 @@ class SS2DCoreFn(torch.autograd.Function):
         y = torch.empty((Bsz, D, L), device=dev, dtype=torch.float32)
         mu = torch.empty((Bsz, L), device=dev, dtype=torch.float32)
         rstd = torch.empty((Bsz, L), device=dev, dtype=torch.float32)
-        with torch.cuda.device(dev):
+        with _lib.device_guard(dev):
             rc = lib.mm_cross_merge_fwd(out4.data_ptr(), m.data_ptr(), Bsz, D, H, W, _stream())
             _lib.check(rc, "mm_cross_merge_fwd")
             rc = lib.mm_ln_gate_fwd(m.data_ptr(), z_cf.data_ptr(), z_cf.stride(0), ln_w.data_ptr(), ln_b.data_ptr(), float(eps),
@@ -224,7 +226,7 @@ class SS2DCoreFn(torch.autograd.Function):
         dz = torch.empty((Bsz, D, L), device=dev, dtype=torch.float32)
         lib = _lib.lib()
         ws = torch.empty((lib.mm_ln_gate_rows(Bsz, L), 2 * D), device=dev, dtype=torch.float32)
-        with torch.cuda.device(dev):
+        with _lib.device_guard(dev):
             rc = lib.mm_ln_gate_bwd(dy.data_ptr(), m.data_ptr(), z_cf.data_ptr(), z_cf.stride(0), ln_w.data_ptr(), ln_b.data_ptr(),
                                     mu.data_ptr(), rstd.data_ptr(), dout2.data_ptr(), dout2.stride(0), dz.data_ptr(),
                                     dz.stride(0), ws.data_ptr(), Bsz, D, L, _stream())
@@ -236,7 +238,7 @@ class SS2DCoreFn(torch.autograd.Function):
         # gradient of the packed parameters: the A / D / bias segments are accumulated with atomics -> one zero-fill
         dP = torch.empty_like(P)
         dWx, dWdt, dA, dD, ddb = SS2DCoreFn._segments(dP, D, C, R, N)
-        dP[4 * C * D + 4 * D * R:].zero_()
+        dP[dA.storage_offset() - dP.storage_offset():].zero_()
         dx_dbl = torch.zeros((Bsz, 4, C, L), device=dev, dtype=torch.float32)    # dB/dC are accumulated (atomics for D > 128)
         du4, ddelta = _launch_bwd(u2, delta, A, x_dbl[:, :, R:R + N], x_dbl[:, :, R + N:], Dp, dbias, x_chk, dout2, True,
                                   _CROSS_SHARED, dBC=(dx_dbl[:, :, R:R + N], dx_dbl[:, :, R + N:]), dparams=(dA, dD, ddb))[:2]
@@ -252,7 +254,7 @@ class SS2DCoreFn(torch.autograd.Function):
                      dxd2.reshape(Bsz * 2, 2 * C, L))                                       # + Wx^T d(x_dbl)
         torch.sum(torch.matmul(dxd2, u2.view(Bsz, 2, D, L).transpose(-1, -2)), 0, out=dWx.view(2, 2 * C, D))
         G = torch.empty_like(P)
-        with torch.cuda.device(dev):
+        with _lib.device_guard(dev):
             rc = lib.mm_ss2d_pack_bwd(dP.data_ptr(), P.data_ptr(), G.data_ptr(), D, C, R, N, _stream())
         _lib.check(rc, "mm_ss2d_pack_bwd")
         gWx, gWdt, gA, gD, gb = SS2DCoreFn._segments(G, D, C, R, N)
@@ -285,7 +287,7 @@ class BlockSplitFn(torch.autograd.Function):
         rn = torch.empty((B, H, W, C2), device=dev, dtype=torch.float32)
         mu = torch.empty((B * P,), device=dev, dtype=torch.float32)
         rstd = torch.empty((B * P,), device=dev, dtype=torch.float32)
-        with torch.cuda.device(dev):
+        with _lib.device_guard(dev):
             rc = _lib.lib().mm_block_split_fwd(inp.data_ptr(), gamma.data_ptr(), beta.data_ptr(), float(eps), left.data_ptr(),
                                                rn.data_ptr(), mu.data_ptr(), rstd.data_ptr(), B, P, C2, _stream())
         _lib.check(rc, "mm_block_split_fwd")
@@ -302,7 +304,7 @@ class BlockSplitFn(torch.autograd.Function):
         dinp = torch.empty_like(inp)
         lib = _lib.lib()
         ws = torch.empty((lib.mm_block_split_rows(B, P, C2), 2 * C2), device=dev, dtype=torch.float32)
-        with torch.cuda.device(dev):
+        with _lib.device_guard(dev):
             rc = lib.mm_block_split_bwd(dleft.data_ptr(), drn.data_ptr(), inp.data_ptr(), gamma.data_ptr(), mu.data_ptr(),
                                         rstd.data_ptr(), dinp.data_ptr(), ws.data_ptr(), B, P, C2, _stream())
         _lib.check(rc, "mm_block_split_bwd")

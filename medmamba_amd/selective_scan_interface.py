@@ -122,9 +122,9 @@ def _launch_fwd(u, delta, A, B, C, D, delta_bias, delta_softplus, want_chk, vari
     _fill_common(a, u, delta, A, B, C, D, delta_bias, delta_softplus)
     a.out, a.x_chk, a.variant = out.data_ptr(), _ptr(x_chk), int(variant)
     a.u_groups, a.u_map, a.rev_mask = shared
-    with torch.cuda.device(u.device):
+    with _lib.device_guard(u.device):
         t0 = KERNEL_TIMER.start()
-        rc = _lib.lib().mm_scan_fwd(a, torch.cuda.current_stream().cuda_stream)
+        rc = _lib.lib().mm_scan_fwd(a, _lib.raw_stream())
         KERNEL_TIMER.stop("scan_fwd", t0, scan_bytes_fwd(batch, dim, L, A.shape[1], B.shape[1]))
     _lib.check(rc, "mm_scan_fwd")
     return out, x_chk
@@ -162,9 +162,9 @@ def _launch_bwd(u, delta, A, B, C, D, delta_bias, x_chk, dout, delta_softplus, s
     if dBC is not None:
         a.dB_sb, a.dB_sg, a.dB_sn = dB.stride(0), dB.stride(1), dB.stride(2)
         a.dC_sb, a.dC_sg, a.dC_sn = dC.stride(0), dC.stride(1), dC.stride(2)
-    with torch.cuda.device(dev):
+    with _lib.device_guard(dev):
         t0 = KERNEL_TIMER.start()
-        rc = _lib.lib().mm_scan_bwd(a, torch.cuda.current_stream().cuda_stream)
+        rc = _lib.lib().mm_scan_bwd(a, _lib.raw_stream())
         KERNEL_TIMER.stop("scan_bwd", t0, scan_bytes_bwd(batch, dim, L, N, G))
     _lib.check(rc, "mm_scan_bwd")
     return du, ddelta, dA, dB, dC, dD, dbias

@@ -21,6 +21,17 @@ def main():
         a = agg[short(r["Kernel_Name"])]; a[0] += 1; a[1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
     busy = sum(v[1] for v in agg.values())
     print(f"# source: {f}\n# last step: {len(last)} launches, wall {(t1-t0)/1e6:.3f} ms, sum of kernel time {busy/1e3:.3f} ms")
+    qs = collections.defaultdict(lambda: [0, 0.0])
+    for r in last:
+        q = qs[r.get("Queue_Id", "?")]; q[0] += 1; q[1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    ev = sorted([(int(r["Start_Timestamp"]), 1) for r in last] + [(int(r["End_Timestamp"]), -1) for r in last])
+    depth, prev, union, both = 0, ev[0][0], 0, 0
+    for t, d in ev:
+        if depth > 0: union += t - prev
+        if depth > 1: both += t - prev
+        depth += d; prev = t
+    print("# per HSA queue: " + ", ".join(f"q{k}: {n} launches {us/1e3:.2f} ms" for k, (n, us) in sorted(qs.items())))
+    print(f"# GPU busy (union of kernel intervals) {union/1e6:.3f} ms, >=2 kernels in flight {both/1e6:.3f} ms")
     print(f"{'kernel':<102} {'calls':>6} {'total_us':>10} {'avg_us':>9} {'pct':>6}")
     for k, (n, us) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:top]:
         print(f"{k:<102} {n:>6} {us:>10.1f} {us/n:>9.2f} {100*us/busy:>6.2f}")
