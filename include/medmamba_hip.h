@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MM_ABI_VERSION 5
+#define MM_ABI_VERSION 6
 
 enum mm_status {
   MM_OK = 0,
@@ -101,6 +101,10 @@ typedef struct mm_scan_args {
    * receive dB/dC directly inside the gradient of x_dbl (MedMamba.py:261: B and C are row blocks of x_dbl). */
   int64_t dB_sb, dB_sg, dB_sn;
   int64_t dC_sb, dC_sg, dC_sn;
+  /* backward: element strides of dout / du / ddelta rows; all zero = contiguous.  dout rows at dout + b*dout_sb + d*o_sd,
+   * du and ddelta rows at base + b*dud_sb + d*o_sd (one channel stride for the three).  Lets them live in channel-major
+   * planes (channel, batch, L) where the projections around the scan are single large GEMMs. */
+  int64_t dout_sb, dud_sb, o_sd;
 } mm_scan_args;
 
 /* replaces selective_scan_cuda.fwd behind selective_scan_fn (MedMamba.py:273-279) */
@@ -118,37 +122,50 @@ int mm_scan_chunk(void);
  *   left_relu != 0 : `left` is the PRE-activation of the conv branch's trailing nn.ReLU (MedMamba.py:347), applied here;
  *   ssm_scale (batch) or NULL: per-sample DropPath factor mask/keep_prob of self.drop_path (MedMamba.py:335, 353).
  * Backward: dleft (batch, C2, P) and dssm (same layout as ssm) from dout (batch, P, 2*C2); d(inp) = dout;
- *   left_pre = the same pre-activation (ReLU mask) or NULL. */
-int mm_shuffle_residual_fwd(const float* left, const float* ssm, const float* inp, float* out, const float* ssm_scale,
-                            int left_relu, int batch, int P, int C2, int ssm_channel_first, void* stream);
-int mm_shuffle_residual_bwd(const float* dout, float* dleft, float* dssm, const float* ssm_scale, const float* left_pre,
-                            int batch, int P, int C2, int ssm_channel_first, void* stream);
+ *   left_pre = the same pre-activation (ReLU mask) or NULL.
+ * ssm_sb / ssm_sd (dssm_*): batch / channel element strides of a channel-first ssm (plane (b,i) at ssm + b*sb + i*sd,
+ *   unit stride along P); both 0 = contiguous (batch, C2, P).  Ignored for the NHWC form. */
+int mm_shuffle_residual_fwd(const float* left, const float* ssm, int64_t ssm_sb, int64_t ssm_sd, const float* inp, float* out,
+                            const float* ssm_scale, int left_relu, int batch, int P, int C2, int ssm_channel_first,
+                            void* stream);
+int mm_shuffle_residual_bwd(const float* dout, float* dleft, float* dssm, int64_t dssm_sb, int64_t dssm_sd,
+                            const float* ssm_scale, const float* left_pre, int batch, int P, int C2, int ssm_channel_first,
+                            void* stream);
 
 /* ---- SS2D in channel-first planes (everything between in_proj and out_proj is (batch, channel, H*W)) ----------
+ * Plane tensors are addressed as base + b*X_sb + d*X_sd (element strides, unit stride along H*W), so the same kernels
+ * serve batch-major (batch, D, L) storage (sb = D*L, sd = L) and channel-major (D, batch, L) storage (sb = L,
+ * sd = batch*L) — the latter turns every projection around the scan into one large GEMM over batch*L columns.
  * mm_dwconv_silu_cross_fwd: depthwise conv3x3 (pad 1) + bias + SiLU (MedMamba.py:153-162, 295) that writes the scan's
  *   two input orders directly (replaces the permute of :294 and the stack/transpose of :256):
- *   x planes (b,d) of H*W floats at x + b*x_sb + d*H*W; w (D,1,3,3); bias (D) or NULL;
- *   u2 (batch, 2, D, H*W): u2[b,0,d,h*W+w] = u2[b,1,d,w*H+h] = silu(conv(x)[b,d,h,w] + bias[d]).
- * mm_dwconv_silu_cross_bwd: du2 (batch,2,D,L) -> dx planes (batch stride dx_sb) and per-plane partial sums
+ *   x planes (b,d) of H*W floats at x + b*x_sb + d*x_sd; w (D,1,3,3); bias (D) or NULL;
+ *   u2 = 2*D planes per batch item (plane (b, j*D+d) at u2 + b*u2_sb + (j*D+d)*u2_sd):
+ *   u2[b,0,d,h*W+w] = u2[b,1,d,w*H+h] = silu(conv(x)[b,d,h,w] + bias[d]).
+ * mm_dwconv_silu_cross_bwd: du2 (same plane indexing) -> dx planes and per-plane partial sums
  *   ws[(b*D+d)*10 + (0..8: dW[kh][kw], 9: dbias)]  (the caller sums over b). */
-int mm_dwconv_silu_cross_fwd(const float* x, int64_t x_sb, const float* w, const float* bias, float* u2, int batch, int D,
-                             int H, int W, void* stream);
-int mm_dwconv_silu_cross_bwd(const float* du2, const float* x, int64_t x_sb, const float* w, const float* bias, float* dx,
-                             int64_t dx_sb, float* ws, int batch, int D, int H, int W, void* stream);
+int mm_dwconv_silu_cross_fwd(const float* x, int64_t x_sb, int64_t x_sd, const float* w, const float* bias, float* u2,
+                             int64_t u2_sb, int64_t u2_sd, int batch, int D, int H, int W, void* stream);
+int mm_dwconv_silu_cross_bwd(const float* du2, int64_t du2_sb, int64_t du2_sd, const float* x, int64_t x_sb, int64_t x_sd,
+                             const float* w, const float* bias, float* dx, int64_t dx_sb, int64_t dx_sd, float* ws, int batch,
+                             int D, int H, int W, void* stream);
 /* cross-merge (MedMamba.py:282-286 + the 4-way sum of :298), all tensors in position order:
  *   m[b,d,h*W+w] = out4[b,0,d,h*W+w] + out4[b,1,d,h*W+w] + out4[b,2,d,w*H+h] + out4[b,3,d,w*H+h]
- *   (directions: row-major forward / backward, column-major forward / backward).  out4 (batch,4,D,L), m (batch,D,L). */
-int mm_cross_merge_fwd(const float* out4, float* m, int batch, int D, int H, int W, void* stream);
-/* dst[b,d,w*H+h] = src[b,d,h*W+w]; planes at base + b*sb + d*H*W (adjoint of the column-major half of the merge) */
-int mm_plane_transpose(const float* src, int64_t src_sb, float* dst, int64_t dst_sb, int batch, int D, int H, int W, void* stream);
+ *   (directions: row-major forward / backward, column-major forward / backward).  out4 (batch,4,D,L) contiguous,
+ *   m planes at m + b*m_sb + d*m_sd. */
+int mm_cross_merge_fwd(const float* out4, float* m, int64_t m_sb, int64_t m_sd, int batch, int D, int H, int W, void* stream);
+/* dst[b,d,w*H+h] = src[b,d,h*W+w]; planes at base + b*sb + d*sd (adjoint of the column-major half of the merge) */
+int mm_plane_transpose(const float* src, int64_t src_sb, int64_t src_sd, float* dst, int64_t dst_sb, int64_t dst_sd, int batch,
+                       int D, int H, int W, void* stream);
 /* out_norm LayerNorm over the D channels (eps) + gate with SiLU(z) (MedMamba.py:300-301), channel-first:
  *   y[b,d,p] = ((m[b,d,p]-mu[b,p])*rstd[b,p]*gamma[d]+beta[d]) * silu(z[b,d,p]);  m,y (batch,D,L); z planes with batch
  *   stride z_sb; mu,rstd (batch,L) outputs.  Backward: dm (batch stride dm_sb), dz (batch stride dz_sb) and per-wave
  *   partial sums ws[row*2*D + (0: dgamma, D: dbeta) + d] for row < mm_ln_gate_rows(batch, L) (the caller sums rows). */
-int mm_ln_gate_fwd(const float* m, const float* z, int64_t z_sb, const float* gamma, const float* beta, float eps, float* y,
-                   float* mu, float* rstd, int batch, int D, int L, void* stream);
-int mm_ln_gate_bwd(const float* dy, const float* m, const float* z, int64_t z_sb, const float* gamma, const float* beta,
-                   const float* mu, const float* rstd, float* dm, int64_t dm_sb, float* dz, int64_t dz_sb, float* ws, int batch,
+int mm_ln_gate_fwd(const float* m, int64_t m_sb, int64_t m_sd, const float* z, int64_t z_sb, int64_t z_sd, const float* gamma,
+                   const float* beta, float eps, float* y, int64_t y_sb, int64_t y_sd, float* mu, float* rstd, int batch, int D,
+                   int L, void* stream);
+int mm_ln_gate_bwd(const float* dy, int64_t dy_sb, int64_t dy_sd, const float* m, int64_t m_sb, int64_t m_sd, const float* z,
+                   int64_t z_sb, int64_t z_sd, const float* gamma, const float* beta, const float* mu, const float* rstd,
+                   float* dm, int64_t dm_sb, int64_t dm_sd, float* dz, int64_t dz_sb, int64_t dz_sd, float* ws, int batch,
                    int D, int L, void* stream);
 int mm_ln_gate_rows(int batch, int L);
 

@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "lib", "libmedmamba_hip.so")
 
 _f32p = ctypes.c_void_p
+_i64 = ctypes.c_int64
 
 
 class ScanArgs(ctypes.Structure):
@@ -31,6 +32,7 @@ class ScanArgs(ctypes.Structure):
         ("rev_mask", ctypes.c_uint32),
         ("dB_sb", ctypes.c_int64), ("dB_sg", ctypes.c_int64), ("dB_sn", ctypes.c_int64),
         ("dC_sb", ctypes.c_int64), ("dC_sg", ctypes.c_int64), ("dC_sn", ctypes.c_int64),
+        ("dout_sb", ctypes.c_int64), ("dud_sb", ctypes.c_int64), ("o_sd", ctypes.c_int64),
     ]
 
 
@@ -41,22 +43,22 @@ SYMBOLS = {
     "mm_status_string": (ctypes.c_char_p, [ctypes.c_int]),
     "mm_scan_fwd": (ctypes.c_int, [ctypes.POINTER(ScanArgs), ctypes.c_void_p]),
     "mm_scan_bwd": (ctypes.c_int, [ctypes.POINTER(ScanArgs), ctypes.c_void_p]),
-    "mm_shuffle_residual_fwd": (ctypes.c_int, [_f32p] * 5 + [ctypes.c_int] * 5 + [ctypes.c_void_p]),
-    "mm_dwconv_silu_cross_fwd": (ctypes.c_int, [_f32p, ctypes.c_int64, _f32p, _f32p, _f32p] + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
-    "mm_dwconv_silu_cross_bwd": (ctypes.c_int, [_f32p, _f32p, ctypes.c_int64, _f32p, _f32p, _f32p, ctypes.c_int64, _f32p]
+    "mm_shuffle_residual_fwd": (ctypes.c_int, [_f32p, _f32p, _i64, _i64, _f32p, _f32p, _f32p] + [ctypes.c_int] * 5 + [ctypes.c_void_p]),
+    "mm_dwconv_silu_cross_fwd": (ctypes.c_int, [_f32p, _i64, _i64, _f32p, _f32p, _f32p, _i64, _i64] + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
+    "mm_dwconv_silu_cross_bwd": (ctypes.c_int, [_f32p, _i64, _i64, _f32p, _i64, _i64, _f32p, _f32p, _f32p, _i64, _i64, _f32p]
                                  + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
-    "mm_cross_merge_fwd": (ctypes.c_int, [_f32p, _f32p] + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
-    "mm_plane_transpose": (ctypes.c_int, [_f32p, ctypes.c_int64, _f32p, ctypes.c_int64] + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
-    "mm_ln_gate_fwd": (ctypes.c_int, [_f32p, _f32p, ctypes.c_int64, _f32p, _f32p, ctypes.c_float, _f32p, _f32p, _f32p]
-                       + [ctypes.c_int] * 3 + [ctypes.c_void_p]),
-    "mm_ln_gate_bwd": (ctypes.c_int, [_f32p, _f32p, _f32p, ctypes.c_int64, _f32p, _f32p, _f32p, _f32p, _f32p, ctypes.c_int64,
-                                      _f32p, ctypes.c_int64, _f32p] + [ctypes.c_int] * 3 + [ctypes.c_void_p]),
+    "mm_cross_merge_fwd": (ctypes.c_int, [_f32p, _f32p, _i64, _i64] + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
+    "mm_plane_transpose": (ctypes.c_int, [_f32p, _i64, _i64, _f32p, _i64, _i64] + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
+    "mm_ln_gate_fwd": (ctypes.c_int, [_f32p, _i64, _i64, _f32p, _i64, _i64, _f32p, _f32p, ctypes.c_float, _f32p, _i64, _i64,
+                                      _f32p, _f32p] + [ctypes.c_int] * 3 + [ctypes.c_void_p]),
+    "mm_ln_gate_bwd": (ctypes.c_int, [_f32p, _i64, _i64, _f32p, _i64, _i64, _f32p, _i64, _i64, _f32p, _f32p, _f32p, _f32p,
+                                      _f32p, _i64, _i64, _f32p, _i64, _i64, _f32p] + [ctypes.c_int] * 3 + [ctypes.c_void_p]),
     "mm_ln_gate_rows": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
     "mm_block_split_fwd": (ctypes.c_int, [_f32p, _f32p, _f32p, ctypes.c_float, _f32p, _f32p, _f32p, _f32p] + [ctypes.c_int] * 3
                            + [ctypes.c_void_p]),
     "mm_block_split_bwd": (ctypes.c_int, [_f32p] * 8 + [ctypes.c_int] * 3 + [ctypes.c_void_p]),
     "mm_block_split_rows": (ctypes.c_int, [ctypes.c_int] * 3),
-    "mm_shuffle_residual_bwd": (ctypes.c_int, [_f32p] * 5 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
+    "mm_shuffle_residual_bwd": (ctypes.c_int, [_f32p, _f32p, _f32p, _i64, _i64, _f32p, _f32p] + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
     "mm_ss2d_pack_size": (ctypes.c_int, [ctypes.c_int] * 4),
     "mm_ss2d_pack_fwd": (ctypes.c_int, [_f32p] * 6 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
     "mm_ss2d_pack_bwd": (ctypes.c_int, [_f32p] * 3 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
@@ -84,7 +86,7 @@ def lib():
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(handle, name)      # AttributeError if the .so is stale
             fn.restype, fn.argtypes = res, args
-        if handle.mm_abi_version() != 5:
+        if handle.mm_abi_version() != 6:
             raise MedMambaHipError("libmedmamba_hip.so ABI version mismatch; rebuild")
         _lib = handle
     return _lib

@@ -17,7 +17,7 @@ template <bool SSM_CF>
 __global__ __launch_bounds__(256) void shuffle_residual_fwd_kernel(const float* __restrict__ left, const float* __restrict__ ssm,
                                                                    const float* __restrict__ inp, float* __restrict__ out,
                                                                    const float* __restrict__ ssm_scale, int left_relu,
-                                                                   int P, int C2) {
+                                                                   int64_t ssm_sb, int64_t ssm_sd, int P, int C2) {
   __shared__ float tile[32][33];
   __shared__ float tile2[SSM_CF ? 32 : 1][33];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -30,7 +30,7 @@ __global__ __launch_bounds__(256) void shuffle_residual_fwd_kernel(const float* 
   for (int r = ty; r < 32; r += 8) {
     const int i = i0 + r, p = p0 + tx;
     tile[r][tx] = (i < C2 && p < P) ? lb[(int64_t)i * P + p] : 0.f;
-    if constexpr (SSM_CF) tile2[r][tx] = (i < C2 && p < P) ? ssm[((int64_t)b * C2 + i) * P + p] : 0.f;
+    if constexpr (SSM_CF) tile2[r][tx] = (i < C2 && p < P) ? ssm[b * ssm_sb + i * ssm_sd + p] : 0.f;
   }
   __syncthreads();
   // out rows: position p0+r, channel pair i0+tx (lanes along i)
@@ -50,7 +50,8 @@ __global__ __launch_bounds__(256) void shuffle_residual_fwd_kernel(const float* 
 template <bool SSM_CF>
 __global__ __launch_bounds__(256) void shuffle_residual_bwd_kernel(const float* __restrict__ dout, float* __restrict__ dleft,
                                                                    float* __restrict__ dssm, const float* __restrict__ ssm_scale,
-                                                                   const float* __restrict__ left_pre, int P, int C2) {
+                                                                   const float* __restrict__ left_pre, int64_t dssm_sb,
+                                                                   int64_t dssm_sd, int P, int C2) {
   __shared__ float tile[32][33];
   __shared__ float tile2[SSM_CF ? 32 : 1][33];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(256) void shuffle_residual_bwd_kernel(const float* 
     if (i < C2 && p < P) {
       const bool on = lp ? lp[(int64_t)i * P + p] > 0.0f : true;
       lb[(int64_t)i * P + p] = on ? tile[tx][r] : 0.0f;
-      if constexpr (SSM_CF) dssm[((int64_t)b * C2 + i) * P + p] = tile2[tx][r];
+      if constexpr (SSM_CF) dssm[b * dssm_sb + i * dssm_sd + p] = tile2[tx][r];
     }
   }
 }
@@ -86,25 +87,29 @@ __global__ __launch_bounds__(256) void shuffle_residual_bwd_kernel(const float* 
 
 extern "C" {
 
-int mm_shuffle_residual_fwd(const float* left, const float* ssm, const float* inp, float* out, const float* ssm_scale,
-                            int left_relu, int batch, int P, int C2, int ssm_channel_first, void* stream) {
+int mm_shuffle_residual_fwd(const float* left, const float* ssm, int64_t ssm_sb, int64_t ssm_sd, const float* inp, float* out,
+                            const float* ssm_scale, int left_relu, int batch, int P, int C2, int ssm_channel_first,
+                            void* stream) {
+  if (ssm_sb == 0 && ssm_sd == 0) { ssm_sb = (int64_t)C2 * P; ssm_sd = P; }
   if (!left || !ssm || !inp || !out) return MM_ERR_NULL;
   if (batch <= 0 || P <= 0 || C2 <= 0 || batch > 65535) return MM_ERR_SHAPE;
   if ((reinterpret_cast<uintptr_t>(inp) | reinterpret_cast<uintptr_t>(out)) & 7) return MM_ERR_ALIGN;
   dim3 grid((P + 31) / 32, (C2 + 31) / 32, batch);
-  if (ssm_channel_first) hipLaunchKernelGGL(shuffle_residual_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, left, ssm, inp, out, ssm_scale, left_relu, P, C2);
-  else hipLaunchKernelGGL(shuffle_residual_fwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, left, ssm, inp, out, ssm_scale, left_relu, P, C2);
+  if (ssm_channel_first) hipLaunchKernelGGL(shuffle_residual_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, left, ssm, inp, out, ssm_scale, left_relu, ssm_sb, ssm_sd, P, C2);
+  else hipLaunchKernelGGL(shuffle_residual_fwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, left, ssm, inp, out, ssm_scale, left_relu, ssm_sb, ssm_sd, P, C2);
   return (int)hipGetLastError();
 }
 
-int mm_shuffle_residual_bwd(const float* dout, float* dleft, float* dssm, const float* ssm_scale, const float* left_pre,
-                            int batch, int P, int C2, int ssm_channel_first, void* stream) {
+int mm_shuffle_residual_bwd(const float* dout, float* dleft, float* dssm, int64_t dssm_sb, int64_t dssm_sd,
+                            const float* ssm_scale, const float* left_pre, int batch, int P, int C2, int ssm_channel_first,
+                            void* stream) {
+  if (dssm_sb == 0 && dssm_sd == 0) { dssm_sb = (int64_t)C2 * P; dssm_sd = P; }
   if (!dout || !dleft || !dssm) return MM_ERR_NULL;
   if (batch <= 0 || P <= 0 || C2 <= 0 || batch > 65535) return MM_ERR_SHAPE;
   if (reinterpret_cast<uintptr_t>(dout) & 7) return MM_ERR_ALIGN;
   dim3 grid((P + 31) / 32, (C2 + 31) / 32, batch);
-  if (ssm_channel_first) hipLaunchKernelGGL(shuffle_residual_bwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, dout, dleft, dssm, ssm_scale, left_pre, P, C2);
-  else hipLaunchKernelGGL(shuffle_residual_bwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, dout, dleft, dssm, ssm_scale, left_pre, P, C2);
+  if (ssm_channel_first) hipLaunchKernelGGL(shuffle_residual_bwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, dout, dleft, dssm, ssm_scale, left_pre, dssm_sb, dssm_sd, P, C2);
+  else hipLaunchKernelGGL(shuffle_residual_bwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, dout, dleft, dssm, ssm_scale, left_pre, dssm_sb, dssm_sd, P, C2);
   return (int)hipGetLastError();
 }
 
@@ -121,16 +126,16 @@ namespace {
 // x: planes (b, d) of H*W floats, batch stride x_sb, channel stride H*W.  out u2: (batch, 2, D, L):
 // u2[b,0,d,h*W+w] = u2[b,1,d,w*H+h] = silu(conv(x)[b,d,h,w] + bias[d]).  One workgroup per plane; the plane sits
 // in LDS with a zero halo; the transposed copy goes through a second LDS plane.
-__global__ __launch_bounds__(256) void dwconv_silu_cross_fwd_kernel(const float* __restrict__ x, int64_t x_sb,
+__global__ __launch_bounds__(256) void dwconv_silu_cross_fwd_kernel(const float* __restrict__ x, int64_t x_sb, int64_t x_sd,
                                                                     const float* __restrict__ wgt,
                                                                     const float* __restrict__ bias, float* __restrict__ u2,
-                                                                    int D, int H, int W) {
+                                                                    int64_t u_sb, int64_t u_sd, int D, int H, int W) {
   extern __shared__ float lds[];
   const int b = blockIdx.x / D, d = blockIdx.x % D;
   const int L = H * W, WP = W + 2, tid = threadIdx.x, nt = blockDim.x;
   float* sx = lds;                         // (H+2) x (W+2), zero halo
   float* so = lds + (H + 2) * WP;          // H x (W+1)
-  const float* xp = x + (int64_t)b * x_sb + (int64_t)d * L;
+  const float* xp = x + (int64_t)b * x_sb + (int64_t)d * x_sd;
   for (int i = tid; i < (H + 2) * WP; i += nt) {
     const int hh = i / WP - 1, ww = i % WP - 1;
     sx[i] = (hh >= 0 && hh < H && ww >= 0 && ww < W) ? xp[hh * W + ww] : 0.f;
@@ -140,8 +145,8 @@ __global__ __launch_bounds__(256) void dwconv_silu_cross_fwd_kernel(const float*
   for (int i = 0; i < 9; ++i) k[i] = wgt[d * 9 + i];
   const float bs = bias ? bias[d] : 0.f;
   __syncthreads();
-  float* o0 = u2 + ((int64_t)b * 2 * D + d) * L;
-  float* o1 = u2 + ((int64_t)b * 2 * D + D + d) * L;
+  float* o0 = u2 + b * u_sb + d * u_sd;
+  float* o1 = u2 + b * u_sb + (D + d) * u_sd;
   for (int i = tid; i < L; i += nt) {
     const int h = i / W, w = i % W;
     const float* c = sx + h * WP + w;      // top-left of the 3x3 window
@@ -163,10 +168,12 @@ __global__ __launch_bounds__(256) void dwconv_silu_cross_fwd_kernel(const float*
 
 // backward of the above: g = du2[b,0] + T(du2[b,1]);  dp = g * silu'(p);  dx = corr(dp, flipped k);
 // per-plane partial weight/bias gradients to ws[(b*D+d)*10 + 0..8 | 9].
-__global__ __launch_bounds__(256) void dwconv_silu_cross_bwd_kernel(const float* __restrict__ du2, const float* __restrict__ x,
-                                                                    int64_t x_sb, const float* __restrict__ wgt,
+__global__ __launch_bounds__(256) void dwconv_silu_cross_bwd_kernel(const float* __restrict__ du2, int64_t g_sb, int64_t g_sd,
+                                                                    const float* __restrict__ x, int64_t x_sb, int64_t x_sd,
+                                                                    const float* __restrict__ wgt,
                                                                     const float* __restrict__ bias, float* __restrict__ dx,
-                                                                    int64_t dx_sb, float* __restrict__ ws, int D, int H, int W) {
+                                                                    int64_t dx_sb, int64_t dx_sd, float* __restrict__ ws, int D,
+                                                                    int H, int W) {
   extern __shared__ float lds[];
   const int b = blockIdx.x / D, d = blockIdx.x % D;
   const int L = H * W, WP = W + 2, tid = threadIdx.x, nt = blockDim.x;
@@ -174,9 +181,9 @@ __global__ __launch_bounds__(256) void dwconv_silu_cross_bwd_kernel(const float*
   float* sd = lds + (H + 2) * WP;           // (H+2) x (W+2) dp, zero halo
   float* st = sd + (H + 2) * WP;            // H x (W+1): transposed gradient staging
   __shared__ float red[10][4];
-  const float* xp = x + (int64_t)b * x_sb + (int64_t)d * L;
-  const float* g0 = du2 + ((int64_t)b * 2 * D + d) * L;
-  const float* g1 = du2 + ((int64_t)b * 2 * D + D + d) * L;
+  const float* xp = x + (int64_t)b * x_sb + (int64_t)d * x_sd;
+  const float* g0 = du2 + b * g_sb + d * g_sd;
+  const float* g1 = du2 + b * g_sb + (D + d) * g_sd;
   for (int i = tid; i < (H + 2) * WP; i += nt) {
     const int hh = i / WP - 1, ww = i % WP - 1;
     sx[i] = (hh >= 0 && hh < H && ww >= 0 && ww < W) ? xp[hh * W + ww] : 0.f;
@@ -212,7 +219,7 @@ __global__ __launch_bounds__(256) void dwconv_silu_cross_bwd_kernel(const float*
       for (int kw = 0; kw < 3; ++kw) acc[kh * 3 + kw] = fmaf(dp, c[kh * WP + kw], acc[kh * 3 + kw]);
   }
   __syncthreads();
-  float* dxp = dx + (int64_t)b * dx_sb + (int64_t)d * L;
+  float* dxp = dx + (int64_t)b * dx_sb + (int64_t)d * dx_sd;
   for (int i = tid; i < L; i += nt) {
     const int h = i / W, w = i % W;
     // dx[h,w] = sum_{kh,kw} dp[h-kh+1, w-kw+1] * k[kh][kw]   (sd is offset by +1 in both dims)
@@ -243,7 +250,8 @@ __global__ __launch_bounds__(256) void dwconv_silu_cross_bwd_kernel(const float*
 // ---- cross-merge (MedMamba.py:282-286, 298): m[b,d,h*W+w] = o[b,0,d,hw] + o[b,1,d,hw] + o[b,2,d,wh] + o[b,3,d,wh] ----
 // o: (batch, 4, D, L) in position order (directions: row-major fwd/rev, column-major fwd/rev).  32x32 tiles per plane.
 // grid: ceil(W/32) * ceil(H/32) * batch*D blocks (flattened)
-__global__ __launch_bounds__(256) void cross_merge_fwd_kernel(const float* __restrict__ o, float* __restrict__ m, int D, int H, int W) {
+__global__ __launch_bounds__(256) void cross_merge_fwd_kernel(const float* __restrict__ o, float* __restrict__ m, int64_t m_sb,
+                                                              int64_t m_sd, int D, int H, int W) {
   __shared__ float tile[32][33];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const int nbw = (W + 31) / 32, nbh = (H + 31) / 32;
@@ -265,22 +273,23 @@ __global__ __launch_bounds__(256) void cross_merge_fwd_kernel(const float* __res
     const int h = h0 + r, w = w0 + tx;
     if (h < H && w < W) {
       const int64_t i = (int64_t)h * W + w;
-      m[((int64_t)b * D + d) * L + i] = o0[i] + o1[i] + tile[tx][r];
+      m[b * m_sb + d * m_sd + i] = o0[i] + o1[i] + tile[tx][r];
     }
   }
 }
 
-// plane transpose: dst[pl, w*H+h] = src[pl, h*W+w]; plane pl of batch b / channel d at b*sb + d*L.
-__global__ __launch_bounds__(256) void plane_transpose_kernel(const float* __restrict__ src, int64_t src_sb,
-                                                              float* __restrict__ dst, int64_t dst_sb, int D, int H, int W) {
+// plane transpose: dst[pl, w*H+h] = src[pl, h*W+w]; plane pl of batch b / channel d at b*sb + d*sd.
+__global__ __launch_bounds__(256) void plane_transpose_kernel(const float* __restrict__ src, int64_t src_sb, int64_t src_sd,
+                                                              float* __restrict__ dst, int64_t dst_sb, int64_t dst_sd, int D,
+                                                              int H, int W) {
   __shared__ float tile[32][33];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const int nbw = (W + 31) / 32, nbh = (H + 31) / 32;
   const int w0 = (blockIdx.x % nbw) * 32, h0 = ((blockIdx.x / nbw) % nbh) * 32, pl = blockIdx.x / (nbw * nbh);
   const int b = pl / D, d = pl % D;
   const int64_t L = (int64_t)H * W;
-  const float* s = src + (int64_t)b * src_sb + (int64_t)d * L;
-  float* t = dst + (int64_t)b * dst_sb + (int64_t)d * L;
+  const float* s = src + (int64_t)b * src_sb + (int64_t)d * src_sd;
+  float* t = dst + (int64_t)b * dst_sb + (int64_t)d * dst_sd;
 #pragma unroll
   for (int r = ty; r < 32; r += 8) {
     const int h = h0 + r, w = w0 + tx;
@@ -305,22 +314,24 @@ __device__ __forceinline__ float pos_sum(float v) {   // sum over the 64/PW lane
 }
 
 template <int PW>
-__global__ __launch_bounds__(256) void ln_gate_fwd_kernel(const float* __restrict__ m, const float* __restrict__ z, int64_t z_sb,
+__global__ __launch_bounds__(256) void ln_gate_fwd_kernel(const float* __restrict__ m, int64_t m_sb, int64_t m_sd,
+                                                          const float* __restrict__ z, int64_t z_sb, int64_t z_sd,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                          float eps, float* __restrict__ y, float* __restrict__ mu_out,
-                                                          float* __restrict__ rstd_out, int D, int L, int npos_blocks) {
+                                                          float eps, float* __restrict__ y, int64_t y_sb, int64_t y_sd,
+                                                          float* __restrict__ mu_out, float* __restrict__ rstd_out, int D, int L,
+                                                          int npos_blocks) {
   constexpr int TPP = 64 / PW;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int b = blockIdx.x / npos_blocks, pb = blockIdx.x % npos_blocks;
   const int p = (pb * 4 + wv) * PW + (lane % PW);
   const int ck = lane / PW;                               // channel chunk of this lane
   const bool ok = p < L;
-  const float* mp = m + (int64_t)b * D * L + p;
+  const float* mp = m + (int64_t)b * m_sb + p;
   const float* zp = z + (int64_t)b * z_sb + p;
   const float shift = ok ? mp[0] : 0.f;                   // shifted one-pass variance (shift = channel 0)
   float s1 = 0.f, s2 = 0.f;
   for (int d = ck; d < D; d += TPP) {
-    const float v = ok ? mp[(int64_t)d * L] - shift : 0.f;
+    const float v = ok ? mp[d * m_sd] - shift : 0.f;
     s1 += v;
     s2 = fmaf(v, v, s2);
   }
@@ -334,39 +345,41 @@ __global__ __launch_bounds__(256) void ln_gate_fwd_kernel(const float* __restric
     rstd_out[(int64_t)b * L + p] = rstd;
   }
   if (!ok) return;
-  float* yp = y + (int64_t)b * D * L + p;
+  float* yp = y + (int64_t)b * y_sb + p;
   for (int d = ck; d < D; d += TPP) {
-    const float n = (mp[(int64_t)d * L] - mu) * rstd * gamma[d] + beta[d];
-    const float zz = zp[(int64_t)d * L];
-    yp[(int64_t)d * L] = n * (zz * sigmoid_f(zz));
+    const float n = (mp[d * m_sd] - mu) * rstd * gamma[d] + beta[d];
+    const float zz = zp[d * z_sd];
+    yp[d * y_sd] = n * (zz * sigmoid_f(zz));
   }
 }
 
 // backward: dm (written with batch stride dm_sb), dz (batch stride dz_sb), and per-wave partial sums of
 // dgamma / dbeta to ws[(wave_global) * 2 * D + {0: dgamma, D: dbeta} + d]  (summed by the caller).
 template <int PW>
-__global__ __launch_bounds__(256) void ln_gate_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ m,
-                                                          const float* __restrict__ z, int64_t z_sb,
+__global__ __launch_bounds__(256) void ln_gate_bwd_kernel(const float* __restrict__ dy, int64_t g_sb, int64_t g_sd,
+                                                          const float* __restrict__ m, int64_t m_sb, int64_t m_sd,
+                                                          const float* __restrict__ z, int64_t z_sb, int64_t z_sd,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           const float* __restrict__ mu_in, const float* __restrict__ rstd_in,
-                                                          float* __restrict__ dm, int64_t dm_sb, float* __restrict__ dz,
-                                                          int64_t dz_sb, float* __restrict__ ws, int D, int L, int npos_blocks) {
+                                                          float* __restrict__ dm, int64_t dm_sb, int64_t dm_sd,
+                                                          float* __restrict__ dz, int64_t dz_sb, int64_t dz_sd,
+                                                          float* __restrict__ ws, int D, int L, int npos_blocks) {
   constexpr int TPP = 64 / PW;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int b = blockIdx.x / npos_blocks, pb = blockIdx.x % npos_blocks;
   const int p = (pb * 4 + wv) * PW + (lane % PW);
   const int ck = lane / PW;
   const bool ok = p < L;
-  const float* mp = m + (int64_t)b * D * L + p;
-  const float* gp = dy + (int64_t)b * D * L + p;
+  const float* mp = m + (int64_t)b * m_sb + p;
+  const float* gp = dy + (int64_t)b * g_sb + p;
   const float* zp = z + (int64_t)b * z_sb + p;
   const float mu = ok ? mu_in[(int64_t)b * L + p] : 0.f, rstd = ok ? rstd_in[(int64_t)b * L + p] : 0.f;
   float c1 = 0.f, c2 = 0.f;
   for (int d = ck; d < D; d += TPP) {
     if (ok) {
-      const float zz = zp[(int64_t)d * L];
-      const float dn = gp[(int64_t)d * L] * (zz * sigmoid_f(zz)) * gamma[d];
-      const float xh = (mp[(int64_t)d * L] - mu) * rstd;
+      const float zz = zp[d * z_sd];
+      const float dn = gp[d * g_sd] * (zz * sigmoid_f(zz)) * gamma[d];
+      const float xh = (mp[d * m_sd] - mu) * rstd;
       c1 += dn;
       c2 = fmaf(dn, xh, c2);
     }
@@ -380,13 +393,13 @@ __global__ __launch_bounds__(256) void ln_gate_bwd_kernel(const float* __restric
     const int d = d0 + ck;
     float pg = 0.f, pb_ = 0.f;
     if (ok && d < D) {
-      const float zz = zp[(int64_t)d * L], s = sigmoid_f(zz), sz = zz * s;
-      const float g = gp[(int64_t)d * L];
-      const float xh = (mp[(int64_t)d * L] - mu) * rstd;
+      const float zz = zp[d * z_sd], s = sigmoid_f(zz), sz = zz * s;
+      const float g = gp[d * g_sd];
+      const float xh = (mp[d * m_sd] - mu) * rstd;
       const float n = xh * gamma[d] + beta[d];
       const float dn = g * sz;
-      dzp[(int64_t)d * L] = g * n * (s * (1.f + zz * (1.f - s)));
-      dmp[(int64_t)d * L] = rstd * (dn * gamma[d] - c1 - xh * c2);
+      dzp[d * dz_sd] = g * n * (s * (1.f + zz * (1.f - s)));
+      dmp[d * dm_sd] = rstd * (dn * gamma[d] - c1 - xh * c2);
       pg = dn * xh;
       pb_ = dn;
     }
@@ -413,44 +426,46 @@ inline int pick_pw(int batch, int L) {   // positions per wave: fewer when there
 
 extern "C" {
 
-int mm_dwconv_silu_cross_fwd(const float* x, int64_t x_sb, const float* w, const float* bias, float* u2, int batch, int D,
-                             int H, int W, void* stream) {
+int mm_dwconv_silu_cross_fwd(const float* x, int64_t x_sb, int64_t x_sd, const float* w, const float* bias, float* u2,
+                             int64_t u2_sb, int64_t u2_sd, int batch, int D, int H, int W, void* stream) {
   if (!x || !w || !u2) return MM_ERR_NULL;
   if (batch <= 0 || D <= 0 || H <= 0 || W <= 0) return MM_ERR_SHAPE;
   const size_t lds = sizeof(float) * ((size_t)(H + 2) * (W + 2) + (size_t)H * (W + 1));
   if (lds > 150 * 1024) return MM_ERR_UNSUPPORTED;
   const int L = H * W, nt = L >= 1024 ? 256 : (L > 64 ? 128 : 64);
   if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)dwconv_silu_cross_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(dwconv_silu_cross_fwd_kernel, dim3(batch * D), dim3(nt), lds, (hipStream_t)stream, x, x_sb, w, bias, u2, D, H, W);
+  hipLaunchKernelGGL(dwconv_silu_cross_fwd_kernel, dim3(batch * D), dim3(nt), lds, (hipStream_t)stream, x, x_sb, x_sd, w, bias, u2, u2_sb, u2_sd, D, H, W);
   return (int)hipGetLastError();
 }
 
-int mm_dwconv_silu_cross_bwd(const float* du2, const float* x, int64_t x_sb, const float* w, const float* bias, float* dx,
-                             int64_t dx_sb, float* ws, int batch, int D, int H, int W, void* stream) {
+int mm_dwconv_silu_cross_bwd(const float* du2, int64_t du2_sb, int64_t du2_sd, const float* x, int64_t x_sb, int64_t x_sd,
+                             const float* w, const float* bias, float* dx, int64_t dx_sb, int64_t dx_sd, float* ws, int batch,
+                             int D, int H, int W, void* stream) {
   if (!du2 || !x || !w || !dx || !ws) return MM_ERR_NULL;
   if (batch <= 0 || D <= 0 || H <= 0 || W <= 0) return MM_ERR_SHAPE;
   const size_t lds = sizeof(float) * (2 * (size_t)(H + 2) * (W + 2) + (size_t)H * (W + 1));
   if (lds > 150 * 1024) return MM_ERR_UNSUPPORTED;
   const int L = H * W, nt = L >= 1024 ? 256 : (L > 64 ? 128 : 64);
   if (lds > 60 * 1024) (void)hipFuncSetAttribute((const void*)dwconv_silu_cross_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(dwconv_silu_cross_bwd_kernel, dim3(batch * D), dim3(nt), lds, (hipStream_t)stream, du2, x, x_sb, w, bias,
-                     dx, dx_sb, ws, D, H, W);
+  hipLaunchKernelGGL(dwconv_silu_cross_bwd_kernel, dim3(batch * D), dim3(nt), lds, (hipStream_t)stream, du2, du2_sb, du2_sd, x, x_sb,
+                     x_sd, w, bias, dx, dx_sb, dx_sd, ws, D, H, W);
   return (int)hipGetLastError();
 }
 
-int mm_cross_merge_fwd(const float* out4, float* m, int batch, int D, int H, int W, void* stream) {
+int mm_cross_merge_fwd(const float* out4, float* m, int64_t m_sb, int64_t m_sd, int batch, int D, int H, int W, void* stream) {
   if (!out4 || !m) return MM_ERR_NULL;
   if (batch <= 0 || D <= 0 || H <= 0 || W <= 0) return MM_ERR_SHAPE;
   hipLaunchKernelGGL(cross_merge_fwd_kernel, dim3(((W + 31) / 32) * ((H + 31) / 32) * batch * D), dim3(256), 0, (hipStream_t)stream,
-                     out4, m, D, H, W);
+                     out4, m, m_sb, m_sd, D, H, W);
   return (int)hipGetLastError();
 }
 
-int mm_plane_transpose(const float* src, int64_t src_sb, float* dst, int64_t dst_sb, int batch, int D, int H, int W, void* stream) {
+int mm_plane_transpose(const float* src, int64_t src_sb, int64_t src_sd, float* dst, int64_t dst_sb, int64_t dst_sd, int batch,
+                       int D, int H, int W, void* stream) {
   if (!src || !dst) return MM_ERR_NULL;
   if (batch <= 0 || D <= 0 || H <= 0 || W <= 0) return MM_ERR_SHAPE;
   hipLaunchKernelGGL(plane_transpose_kernel, dim3(((W + 31) / 32) * ((H + 31) / 32) * batch * D), dim3(256), 0, (hipStream_t)stream,
-                     src, src_sb, dst, dst_sb, D, H, W);
+                     src, src_sb, src_sd, dst, dst_sb, dst_sd, D, H, W);
   return (int)hipGetLastError();
 }
 
@@ -459,30 +474,32 @@ int mm_ln_gate_rows(int batch, int L) {   // rows of the dgamma/dbeta workspace 
   return batch * ((L + 4 * pw - 1) / (4 * pw)) * 4;
 }
 
-int mm_ln_gate_fwd(const float* m, const float* z, int64_t z_sb, const float* gamma, const float* beta, float eps, float* y,
-                   float* mu, float* rstd, int batch, int D, int L, void* stream) {
+int mm_ln_gate_fwd(const float* m, int64_t m_sb, int64_t m_sd, const float* z, int64_t z_sb, int64_t z_sd, const float* gamma,
+                   const float* beta, float eps, float* y, int64_t y_sb, int64_t y_sd, float* mu, float* rstd, int batch, int D,
+                   int L, void* stream) {
   if (!m || !z || !gamma || !beta || !y || !mu || !rstd) return MM_ERR_NULL;
   if (batch <= 0 || D <= 0 || L <= 0) return MM_ERR_SHAPE;
   const int pw = pick_pw(batch, L), npb = (L + 4 * pw - 1) / (4 * pw);
   const dim3 grid(batch * npb), blk(256);
   hipStream_t s = (hipStream_t)stream;
-  if (pw == 64) hipLaunchKernelGGL(ln_gate_fwd_kernel<64>, grid, blk, 0, s, m, z, z_sb, gamma, beta, eps, y, mu, rstd, D, L, npb);
-  else if (pw == 16) hipLaunchKernelGGL(ln_gate_fwd_kernel<16>, grid, blk, 0, s, m, z, z_sb, gamma, beta, eps, y, mu, rstd, D, L, npb);
-  else hipLaunchKernelGGL(ln_gate_fwd_kernel<4>, grid, blk, 0, s, m, z, z_sb, gamma, beta, eps, y, mu, rstd, D, L, npb);
+  if (pw == 64) hipLaunchKernelGGL(ln_gate_fwd_kernel<64>, grid, blk, 0, s, m, m_sb, m_sd, z, z_sb, z_sd, gamma, beta, eps, y, y_sb, y_sd, mu, rstd, D, L, npb);
+  else if (pw == 16) hipLaunchKernelGGL(ln_gate_fwd_kernel<16>, grid, blk, 0, s, m, m_sb, m_sd, z, z_sb, z_sd, gamma, beta, eps, y, y_sb, y_sd, mu, rstd, D, L, npb);
+  else hipLaunchKernelGGL(ln_gate_fwd_kernel<4>, grid, blk, 0, s, m, m_sb, m_sd, z, z_sb, z_sd, gamma, beta, eps, y, y_sb, y_sd, mu, rstd, D, L, npb);
   return (int)hipGetLastError();
 }
 
-int mm_ln_gate_bwd(const float* dy, const float* m, const float* z, int64_t z_sb, const float* gamma, const float* beta,
-                   const float* mu, const float* rstd, float* dm, int64_t dm_sb, float* dz, int64_t dz_sb, float* ws, int batch,
+int mm_ln_gate_bwd(const float* dy, int64_t dy_sb, int64_t dy_sd, const float* m, int64_t m_sb, int64_t m_sd, const float* z,
+                   int64_t z_sb, int64_t z_sd, const float* gamma, const float* beta, const float* mu, const float* rstd,
+                   float* dm, int64_t dm_sb, int64_t dm_sd, float* dz, int64_t dz_sb, int64_t dz_sd, float* ws, int batch,
                    int D, int L, void* stream) {
   if (!dy || !m || !z || !gamma || !beta || !mu || !rstd || !dm || !dz || !ws) return MM_ERR_NULL;
   if (batch <= 0 || D <= 0 || L <= 0) return MM_ERR_SHAPE;
   const int pw = pick_pw(batch, L), npb = (L + 4 * pw - 1) / (4 * pw);
   const dim3 grid(batch * npb), blk(256);
   hipStream_t s = (hipStream_t)stream;
-  if (pw == 64) hipLaunchKernelGGL(ln_gate_bwd_kernel<64>, grid, blk, 0, s, dy, m, z, z_sb, gamma, beta, mu, rstd, dm, dm_sb, dz, dz_sb, ws, D, L, npb);
-  else if (pw == 16) hipLaunchKernelGGL(ln_gate_bwd_kernel<16>, grid, blk, 0, s, dy, m, z, z_sb, gamma, beta, mu, rstd, dm, dm_sb, dz, dz_sb, ws, D, L, npb);
-  else hipLaunchKernelGGL(ln_gate_bwd_kernel<4>, grid, blk, 0, s, dy, m, z, z_sb, gamma, beta, mu, rstd, dm, dm_sb, dz, dz_sb, ws, D, L, npb);
+  if (pw == 64) hipLaunchKernelGGL(ln_gate_bwd_kernel<64>, grid, blk, 0, s, dy, dy_sb, dy_sd, m, m_sb, m_sd, z, z_sb, z_sd, gamma, beta, mu, rstd, dm, dm_sb, dm_sd, dz, dz_sb, dz_sd, ws, D, L, npb);
+  else if (pw == 16) hipLaunchKernelGGL(ln_gate_bwd_kernel<16>, grid, blk, 0, s, dy, dy_sb, dy_sd, m, m_sb, m_sd, z, z_sb, z_sd, gamma, beta, mu, rstd, dm, dm_sb, dm_sd, dz, dz_sb, dz_sd, ws, D, L, npb);
+  else hipLaunchKernelGGL(ln_gate_bwd_kernel<4>, grid, blk, 0, s, dy, dy_sb, dy_sd, m, m_sb, m_sd, z, z_sb, z_sd, gamma, beta, mu, rstd, dm, dm_sb, dm_sd, dz, dz_sb, dz_sd, ws, D, L, npb);
   return (int)hipGetLastError();
 }
 

@@ -40,6 +40,7 @@ struct BwdParams {
   float* __restrict__ dbias;
   int64_t u_sb, u_sd, d_sb, d_sd, B_sb, B_sg, B_sn, C_sb, C_sg, C_sn;
   int64_t dB_sb, dB_sg, dB_sn, dC_sb, dC_sg, dC_sn;
+  int64_t g_sb, o_sb, o_sd;  // batch stride of dout; batch stride of du / ddelta; channel stride shared by all three
   int dim, L, G, H, CW, ncw, ntiles, nchk;
   int ug;                   // channel blocks in u / dout
   unsigned u_map, rev_mask; // block of group g = (u_map >> 4g) & 15; bit g of rev_mask: group g runs backwards
@@ -104,11 +105,13 @@ __global__ __launch_bounds__(512) void scan_bwd_kernel(const BwdParams p) {
   const int hc0 = cw * p.CW + wave * CH + r;
   const int d0 = grp * p.H + cw * p.CW + wave * CH;            // first channel of this wave (uniform)
   const int d0u = ugrp * p.H + cw * p.CW + wave * CH;
-  const rsrc_t ru = make_rsrc(p.u + b * p.u_sb + d0u * p.u_sd, ((int64_t)(p.ug * p.H - d0u - 1) * p.u_sd + p.L) * 4);
-  const rsrc_t rd = make_rsrc(p.delta + b * p.d_sb + d0 * p.d_sd, ((int64_t)(p.dim - d0 - 1) * p.d_sd + p.L) * 4);
-  const rsrc_t rg = make_rsrc(p.dout + ((int64_t)b * p.ug * p.H + d0u) * p.L, (int64_t)(p.ug * p.H - d0u) * p.L * 4);
-  const rsrc_t rdu = make_rsrc(p.du + ((int64_t)b * p.dim + d0) * p.L, (int64_t)(p.dim - d0) * p.L * 4);
-  const rsrc_t rdd = make_rsrc(p.ddelta + ((int64_t)b * p.dim + d0) * p.L, (int64_t)(p.dim - d0) * p.L * 4);
+  // descriptors cover exactly this wave's rows: 32-bit offsets suffice for any channel stride (channel-major planes)
+  const int nrw = min(CH, p.H - (cw * p.CW + wave * CH));      // valid rows of this wave (<= 0: empty descriptors)
+  const rsrc_t ru = make_rsrc(p.u + b * p.u_sb + d0u * p.u_sd, ((int64_t)(nrw - 1) * p.u_sd + p.L) * 4);
+  const rsrc_t rd = make_rsrc(p.delta + b * p.d_sb + d0 * p.d_sd, ((int64_t)(nrw - 1) * p.d_sd + p.L) * 4);
+  const rsrc_t rg = make_rsrc(p.dout + b * p.g_sb + d0u * p.o_sd, ((int64_t)(nrw - 1) * p.o_sd + p.L) * 4);
+  const rsrc_t rdu = make_rsrc(p.du + b * p.o_sb + d0 * p.o_sd, ((int64_t)(nrw - 1) * p.o_sd + p.L) * 4);
+  const rsrc_t rdd = make_rsrc(p.ddelta + b * p.o_sb + d0 * p.o_sd, ((int64_t)(nrw - 1) * p.o_sd + p.L) * 4);
   const rsrc_t rB = make_rsrc(p.B + b * p.B_sb + grp * p.B_sg, ((int64_t)(kNState - 1) * p.B_sn + p.L) * 4);
   const rsrc_t rC = make_rsrc(p.C + b * p.C_sb + grp * p.C_sg, ((int64_t)(kNState - 1) * p.C_sn + p.L) * 4);
   float* dBbase = p.dB + b * p.dB_sb + grp * p.dB_sg;
@@ -123,7 +126,7 @@ __global__ __launch_bounds__(512) void scan_bwd_kernel(const BwdParams p) {
     bv[i] = p.bias ? p.bias[dd] : 0.f;
     uoff[i] = (int)((r + RPI * i) * p.u_sd) * 4;
     doff[i] = (int)((r + RPI * i) * p.d_sd) * 4;
-    ooff[i] = ((r + RPI * i) * p.L) * 4;
+    ooff[i] = (int)((r + RPI * i) * p.o_sd) * 4;
     dDacc[i] = 0.f;
     dbacc[i] = 0.f;
   }
@@ -384,8 +387,17 @@ int scan_bwd_launch(const mm_scan_args* a, hipStream_t stream) {
   p.ug = shared ? a->u_groups : a->G;
   p.u_map = shared ? a->u_map : 0x76543210u;
   p.rev_mask = a->rev_mask;
-  const int64_t span = (int64_t)a->dim * (a->u_sd > a->L ? a->u_sd : a->L) * 4;
-  if (span >= 0x7ffffff0ll || (int64_t)kNState * a->B_sn * 4 >= 0x7ffffff0ll) return MM_ERR_UNSUPPORTED;
+  const bool o_strided = a->dout_sb || a->dud_sb || a->o_sd;
+  p.o_sd = o_strided ? a->o_sd : a->L;
+  p.g_sb = o_strided ? a->dout_sb : (int64_t)p.ug * p.H * a->L;
+  p.o_sb = o_strided ? a->dud_sb : (int64_t)a->dim * a->L;
+  int64_t sdmax = a->u_sd > a->delta_sd ? a->u_sd : a->delta_sd;
+  if (p.o_sd > sdmax) sdmax = p.o_sd;
+  const int64_t span = 16 * (sdmax > a->L ? sdmax : a->L) * 4;       // one wave touches <= 16 rows
+  int64_t snmax = a->B_sn > a->C_sn ? a->B_sn : a->C_sn;
+  if (p.dB_sn > snmax) snmax = p.dB_sn;
+  if (p.dC_sn > snmax) snmax = p.dC_sn;
+  if (span >= 0x7ffffff0ll || (int64_t)kNState * snmax * 4 >= 0x7ffffff0ll) return MM_ERR_UNSUPPORTED;
   const int waves_needed = (p.H + CH - 1) / CH;
   // waves per workgroup: <= 8 (register budget); fewer when (batch, direction) pairs alone cannot fill 256 CUs
   // with two workgroups each — the price is fp32 atomics on dB/dC from the workgroups that share a direction
@@ -402,7 +414,8 @@ int scan_bwd_launch(const mm_scan_args* a, hipStream_t stream) {
   const bool vec = (a->L % 4 == 0) && aligned16(a->u) && aligned16(a->delta) && aligned16(a->B) && aligned16(a->C) &&
                    aligned16(a->dout) && aligned16(a->du) && aligned16(a->ddelta) && a->u_sb % 4 == 0 &&
                    a->u_sd % 4 == 0 && a->delta_sb % 4 == 0 && a->delta_sd % 4 == 0 && a->B_sb % 4 == 0 &&
-                   a->B_sg % 4 == 0 && a->B_sn % 4 == 0 && a->C_sb % 4 == 0 && a->C_sg % 4 == 0 && a->C_sn % 4 == 0;
+                   a->B_sg % 4 == 0 && a->B_sn % 4 == 0 && a->C_sb % 4 == 0 && a->C_sg % 4 == 0 && a->C_sn % 4 == 0 &&
+                   p.o_sd % 4 == 0 && p.g_sb % 4 == 0 && p.o_sb % 4 == 0;
   const bool sp = a->delta_softplus != 0;
   if (vec) return sp ? launch<true, true>(p, nblocks, waves, stream) : launch<true, false>(p, nblocks, waves, stream);
   return sp ? launch<false, true>(p, nblocks, waves, stream) : launch<false, false>(p, nblocks, waves, stream);

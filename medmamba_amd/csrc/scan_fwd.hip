@@ -111,10 +111,12 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(const FwdParams p) {
   const int hc0 = cwv * CH + r;
   const int d0 = grp * p.H + cwv * CH;               // first channel of this wave (wave-uniform)
   const int d0u = ugrp * p.H + cwv * CH;             // ... inside u
-  // descriptors: wave-uniform bases, hardware range check does the tail masking
-  const rsrc_t ru = make_rsrc(p.u + b * p.u_sb + d0u * p.u_sd, ((int64_t)(p.ug * p.H - d0u - 1) * p.u_sd + p.L) * 4);
-  const rsrc_t rd = make_rsrc(p.delta + b * p.d_sb + d0 * p.d_sd, ((int64_t)(p.dim - d0 - 1) * p.d_sd + p.L) * 4);
-  const rsrc_t ro = make_rsrc(p.out + ((int64_t)b * p.dim + d0) * p.L, (int64_t)(p.dim - d0) * p.L * 4);
+  // descriptors: wave-uniform bases that cover exactly this wave's rows (so 32-bit offsets suffice for any channel
+  // stride, e.g. channel-major planes with stride batch*L); the hardware range check does the tail masking
+  const int nrw = min(CH, p.H - cwv * CH);           // valid rows of this wave (<= 0: empty descriptors)
+  const rsrc_t ru = make_rsrc(p.u + b * p.u_sb + d0u * p.u_sd, ((int64_t)(nrw - 1) * p.u_sd + p.L) * 4);
+  const rsrc_t rd = make_rsrc(p.delta + b * p.d_sb + d0 * p.d_sd, ((int64_t)(nrw - 1) * p.d_sd + p.L) * 4);
+  const rsrc_t ro = make_rsrc(p.out + ((int64_t)b * p.dim + d0) * p.L, (int64_t)nrw * p.L * 4);
   const rsrc_t rB = make_rsrc(p.B + b * p.B_sb + grp * p.B_sg, ((int64_t)(kNState - 1) * p.B_sn + p.L) * 4);
   const rsrc_t rC = make_rsrc(p.C + b * p.C_sb + grp * p.C_sg, ((int64_t)(kNState - 1) * p.C_sn + p.L) * 4);
   float Dv[NLD], bv[NLD];
@@ -335,8 +337,10 @@ int scan_fwd_launch(const mm_scan_args* a, hipStream_t stream) {
   const int CH = 4 * ns;
   p.wpg = (p.H + CH - 1) / CH;
   // 32-bit byte offsets inside one batch item must not overflow
-  const int64_t span = (int64_t)a->dim * (a->u_sd > a->L ? a->u_sd : a->L) * 4;
-  if (span >= 0x7ffffff0ll || (int64_t)kNState * a->B_sn * 4 >= 0x7ffffff0ll) return MM_ERR_UNSUPPORTED;
+  const int64_t sdmax = a->u_sd > a->delta_sd ? a->u_sd : a->delta_sd;
+  const int64_t span = 16 * (sdmax > a->L ? sdmax : a->L) * 4;       // one wave touches <= 16 rows
+  if (span >= 0x7ffffff0ll || (int64_t)kNState * (a->B_sn > a->C_sn ? a->B_sn : a->C_sn) * 4 >= 0x7ffffff0ll)
+    return MM_ERR_UNSUPPORTED;
   p.nwaves_total = a->batch * a->G * p.wpg;
   int nblocks = (p.nwaves_total + wpb - 1) / wpb;
   nblocks = (nblocks + 7) & ~7;             // multiple of 8 so the XCD remap is a bijection; surplus waves exit

@@ -24,7 +24,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 import torch.utils.checkpoint as checkpoint
 
-from .ops import block_split, dwconv_silu_cross, in_proj_cf, shuffle_residual, ss2d_core
+from .ops import block_split, dwconv_silu_cross, in_proj_cf, out_proj_cf, shuffle_residual, ss2d_core
 from .selective_scan_interface import CROSS_SCAN_K_OF_G, cross_scan_fn, selective_scan_fn
 
 trunc_normal_ = nn.init.trunc_normal_   # timm.layers.trunc_normal_ == torch.nn.init.trunc_normal_
@@ -229,9 +229,11 @@ class SS2D(nn.Module):
 
     def forward_cf(self, x):
         """(B, H, W, d_model) -> (B, d_model, H*W), channel-first.  MI355X layout: everything between in_proj and
-        out_proj lives in channel-first planes (B, channel, H*W): in_proj / out_proj are batched GEMMs with a broadcast
-        weight (no copy), the depthwise conv, the scan, the cross-merge, out_norm and the gate are plane-wise HIP
-        kernels, so none of the reference's permute / stack / flip / transpose copies (MedMamba.py:294-299) exists."""
+        out_proj lives in channel-first planes (B, channel, H*W) — stored batch-major for long sequences (projections =
+        batched GEMMs with a broadcast weight) and channel-major (channel, B, H*W) for short ones (projections = single
+        GEMMs over B*H*W columns; ops.channel_major) — the depthwise conv, the scan, the cross-merge, out_norm and the gate
+        are plane-wise HIP kernels taking (batch, channel) strides, so none of the reference's permute / stack / flip /
+        transpose copies (MedMamba.py:294-299) exists."""
         B, H, W, _ = x.shape
         L, D, R, N = H * W, self.d_inner, self.dt_rank, self.d_state
         x_cf, z_cf = in_proj_cf(x.reshape(B, L, -1), self.in_proj.weight, self.in_proj.bias)  # :291-292, (B, D, L) each
@@ -240,9 +242,7 @@ class SS2D(nn.Module):
         # as the module holds them, the kernel-order packing is one launch inside
         y_cf = ss2d_core(u2, self.x_proj_weight, self.dt_projs_weight, self.dt_projs_bias, self.A_logs, self.Ds,
                          z_cf, self.out_norm.weight, self.out_norm.bias, H, W, self.out_norm.eps)
-        out = torch.bmm(self.out_proj.weight.unsqueeze(0).expand(B, -1, -1), y_cf)           # :302, (B, d_model, L)
-        if self.out_proj.bias is not None:
-            out = out + self.out_proj.bias[:, None]
+        out = out_proj_cf(y_cf, self.out_proj.weight, self.out_proj.bias)                    # :302, (B, d_model, L)
         return out if self.dropout is None else self.dropout(out)
 
     def forward(self, x, **kwargs):

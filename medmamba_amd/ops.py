@@ -1,4 +1,6 @@
 """Autograd wrappers of the glue kernels in libmedmamba_hip.so (csrc/glue.hip) — HIP tensors only."""
+import os
+
 import torch
 
 from . import _lib
@@ -14,29 +16,81 @@ def _need_hip(*ts):
             raise RuntimeError("medmamba_amd.ops: tensors must live on a HIP device (there is no CPU path)")
 
 
+# ---- storage layout of the (B, channel, L) plane tensors between in_proj and out_proj -------------------------------
+# batch-major  : storage (B, D, L) — the projections are batched GEMMs over B (each D x L) plus a sum over B for weights;
+# channel-major: storage (D, B, L), handed around as the permuted view (B, D, L) with strides (L, B*L, 1) — the
+#                projections are single GEMMs with B*L columns.  Measured on MI355X (tools/bench_gemm_layouts.py, S, B=64):
+#                per block 714 -> 458 us at L=196 and 582 -> 342 us at L=49, but 1086 -> 1880 us at L=3136 (hipBLASLt has no
+#                good split-K for K = B*L ~ 2e5), hence channel-major only for short sequences.
+# Every plane kernel takes (batch stride, channel stride), so both layouts run the same code.
+_LAYOUT = os.environ.get("MM_LAYOUT", "auto")          # "auto" | "bm" | "cm" (tests force both)
+
+
+def channel_major(B, L):
+    if _LAYOUT == "cm":
+        return True
+    if _LAYOUT == "bm":
+        return False
+    return B > 1 and L <= 256
+
+
+def _planes(B, D, L, device, cm):
+    """Uninitialised fp32 (B, D, L) planes in the requested storage layout."""
+    if cm:
+        return torch.empty((D, B, L), device=device, dtype=torch.float32).permute(1, 0, 2)
+    return torch.empty((B, D, L), device=device, dtype=torch.float32)
+
+
+def _rows(t):
+    """fp32 with unit stride along L (any batch / channel strides)."""
+    t = t.float()
+    return t if t.stride(-1) == 1 else t.contiguous()
+
+
+def _is_cm(t):
+    B, D, L = t.shape
+    return t.stride(2) == 1 and t.stride(1) == B * L and (B == 1 or t.stride(0) == L)
+
+
+def _cm2d(t):
+    """(D, B*L) matrix over the storage of a channel-major (B, D, L) tensor (a copy is made for any other layout)."""
+    B, D, L = t.shape
+    if not _is_cm(t):
+        t = t.permute(1, 0, 2).contiguous().permute(1, 0, 2)
+    return t.permute(1, 0, 2).reshape(D, B * L)
+
+
+def _pl(t):
+    """(pointer, batch stride, channel stride) of a (B, D, L) plane tensor with unit stride along L."""
+    assert t.stride(2) == 1 or t.shape[2] == 1
+    return t.data_ptr(), t.stride(0), t.stride(1)
+
+
 class ShuffleResidualFn(torch.autograd.Function):
     """out = channel_shuffle(cat(left_nhwc, ssm), 2) + inp   (MedMamba.py:354-357) in one kernel.
     left: (B, C/2, H, W) NCHW conv-branch output; ssm: SS2D-branch output, (B, H, W, C/2) or — channel_first —
-    (B, C/2, H*W); inp: (B, H, W, C).  Optionally folds in the two neighbours of the chain: left_relu — `left` is the
-    pre-activation of the conv branch's trailing ReLU (MedMamba.py:347); ssm_scale (B,) — the DropPath factor
-    mask / keep_prob of every sample (MedMamba.py:335, 353)."""
+    (B, C/2, H*W) planes in either storage layout; inp: (B, H, W, C).  Optionally folds in the two neighbours of the
+    chain: left_relu — `left` is the pre-activation of the conv branch's trailing ReLU (MedMamba.py:347); ssm_scale (B,) —
+    the DropPath factor mask / keep_prob of every sample (MedMamba.py:335, 353)."""
 
     @staticmethod
     def forward(ctx, left, ssm, inp, channel_first, ssm_scale, left_relu):
-        left, ssm, inp = left.float().contiguous(), ssm.float().contiguous(), inp.float().contiguous()
+        left, inp = left.float().contiguous(), inp.float().contiguous()
+        ssm = _rows(ssm) if channel_first else ssm.float().contiguous()
         B, C2, H, W = left.shape
         if ssm_scale is not None:
             ssm_scale = ssm_scale.float().contiguous()
             assert ssm_scale.numel() == B
         out = torch.empty_like(inp)
+        sb, sd = (ssm.stride(0), ssm.stride(1)) if channel_first else (0, 0)
         with _lib.device_guard(inp.device):
-            rc = _lib.lib().mm_shuffle_residual_fwd(left.data_ptr(), ssm.data_ptr(), inp.data_ptr(), out.data_ptr(),
+            rc = _lib.lib().mm_shuffle_residual_fwd(left.data_ptr(), ssm.data_ptr(), sb, sd, inp.data_ptr(), out.data_ptr(),
                                                     None if ssm_scale is None else ssm_scale.data_ptr(), int(bool(left_relu)),
                                                     B, H * W, C2, int(channel_first), _stream())
         _lib.check(rc, "mm_shuffle_residual_fwd")
         ctx.shape = (B, C2, H, W)
         ctx.cf = bool(channel_first)
-        ctx.relu = bool(left_relu)
+        ctx.cm = bool(channel_first) and _is_cm(ssm) and B > 1
         ctx.save_for_backward(ssm_scale, left if left_relu else None)
         return out
 
@@ -46,9 +100,14 @@ class ShuffleResidualFn(torch.autograd.Function):
         ssm_scale, left_pre = ctx.saved_tensors
         dout = dout.float().contiguous()
         dleft = torch.empty((B, C2, H, W), device=dout.device, dtype=torch.float32)
-        dssm = torch.empty((B, C2, H * W) if ctx.cf else (B, H, W, C2), device=dout.device, dtype=torch.float32)
+        if ctx.cf:
+            dssm = _planes(B, C2, H * W, dout.device, ctx.cm)      # same storage layout as ssm: out_proj's backward GEMM
+            sb, sd = dssm.stride(0), dssm.stride(1)
+        else:
+            dssm = torch.empty((B, H, W, C2), device=dout.device, dtype=torch.float32)
+            sb, sd = 0, 0
         with _lib.device_guard(dout.device):
-            rc = _lib.lib().mm_shuffle_residual_bwd(dout.data_ptr(), dleft.data_ptr(), dssm.data_ptr(),
+            rc = _lib.lib().mm_shuffle_residual_bwd(dout.data_ptr(), dleft.data_ptr(), dssm.data_ptr(), sb, sd,
                                                     None if ssm_scale is None else ssm_scale.data_ptr(),
                                                     None if left_pre is None else left_pre.data_ptr(),
                                                     B, H * W, C2, int(ctx.cf), _stream())
@@ -63,18 +122,28 @@ def shuffle_residual(left_nchw, ssm, inp_nhwc, channel_first=False, ssm_scale=No
 
 class InProjFn(torch.autograd.Function):
     """SS2D.in_proj (MedMamba.py:291-292) producing the two channel-first halves without any slicing in autograd:
-    x (B, L, d_model) NHWC rows, weight (2D, d_model)[, bias (2D)] -> (x_cf, z_cf) = two (B, D, L) views of one buffer.
+    x (B, L, d_model) NHWC rows, weight (2D, d_model)[, bias (2D)] -> (x_cf, z_cf) = two (B, D, L) views of one buffer,
+    stored batch-major (a batched GEMM) or channel-major (one GEMM with B*L columns) — see channel_major().
     The backward consumes both gradients directly (no zero-fill / copy / add of sliced activations or weights)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
         Bsz, L, dm = x.shape
         D = weight.shape[0] // 2
-        xz = torch.bmm(weight.unsqueeze(0).expand(Bsz, -1, -1), x.transpose(1, 2))          # (B, 2D, L)
-        if bias is not None:
-            xz += bias[:, None]
+        cm = channel_major(Bsz, L)
+        if cm:
+            x = x.contiguous()
+            xz = torch.mm(weight, x.view(Bsz * L, dm).t())                                    # (2D, B*L)
+            if bias is not None:
+                xz += bias[:, None]
+            xz = xz.view(2 * D, Bsz, L).permute(1, 0, 2)
+        else:
+            xz = torch.bmm(weight.unsqueeze(0).expand(Bsz, -1, -1), x.transpose(1, 2))          # (B, 2D, L)
+            if bias is not None:
+                xz += bias[:, None]
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
+        ctx.cm = cm
         return xz[:, :D], xz[:, D:]
 
     @staticmethod
@@ -83,12 +152,20 @@ class InProjFn(torch.autograd.Function):
         Bsz, L, dm = x.shape
         D = weight.shape[0] // 2
         w0, w1 = weight[:D], weight[D:]
-        # d x (B, L, dm) = dx_cf^T @ W[:D] + dz_cf^T @ W[D:]
-        dx = torch.bmm(dx_cf.transpose(1, 2), w0.unsqueeze(0).expand(Bsz, -1, -1))
-        dx.baddbmm_(dz_cf.transpose(1, 2), w1.unsqueeze(0).expand(Bsz, -1, -1))
         dw = torch.empty_like(weight)
-        torch.sum(torch.bmm(dx_cf, x), dim=0, out=dw[:D])
-        torch.sum(torch.bmm(dz_cf, x), dim=0, out=dw[D:])
+        if ctx.cm:
+            gx, gz, x2 = _cm2d(dx_cf), _cm2d(dz_cf), x.view(Bsz * L, dm)                         # (D, B*L) each
+            dx = torch.mm(gx.t(), w0)
+            dx.addmm_(gz.t(), w1)
+            dx = dx.view(Bsz, L, dm)
+            torch.mm(gx, x2, out=dw[:D])
+            torch.mm(gz, x2, out=dw[D:])
+        else:
+            # d x (B, L, dm) = dx_cf^T @ W[:D] + dz_cf^T @ W[D:]
+            dx = torch.bmm(dx_cf.transpose(1, 2), w0.unsqueeze(0).expand(Bsz, -1, -1))
+            dx.baddbmm_(dz_cf.transpose(1, 2), w1.unsqueeze(0).expand(Bsz, -1, -1))
+            torch.sum(torch.bmm(dx_cf, x), dim=0, out=dw[:D])
+            torch.sum(torch.bmm(dz_cf, x), dim=0, out=dw[D:])
         db = None
         if ctx.has_bias:
             db = torch.cat([dx_cf.sum(dim=(0, 2)), dz_cf.sum(dim=(0, 2))])
@@ -100,28 +177,40 @@ def in_proj_cf(x_rows, weight, bias):
     return InProjFn.apply(x_rows, weight, bias)
 
 
+def out_proj_cf(y_cf, weight, bias=None):
+    """SS2D.out_proj (MedMamba.py:302) on channel-first planes: (B, D, L) -> (B, d_model, L) in the storage layout of y_cf
+    (plain autograd ops: one GEMM over B*L columns for channel-major planes, a batched GEMM otherwise)."""
+    B, D, L = y_cf.shape
+    if B > 1 and _is_cm(y_cf):
+        out = torch.mm(weight, y_cf.permute(1, 0, 2).reshape(D, B * L))
+        if bias is not None:
+            out = out + bias[:, None]
+        return out.view(-1, B, L).permute(1, 0, 2)
+    out = torch.bmm(weight.unsqueeze(0).expand(B, -1, -1), y_cf)
+    return out if bias is None else out + bias[:, None]
+
+
 class DwConvSiluCrossFn(torch.autograd.Function):
     """Depthwise conv3x3 + bias + SiLU on channel-first planes, written in the scan's two image orders
-    (MedMamba.py:153-162, 295 + the stack/transpose of :256).  x_cf: (B, D, L) planes (any batch stride),
-    weight (D,1,3,3), bias (D) or None  ->  u2 (B, 2*D, L)."""
+    (MedMamba.py:153-162, 295 + the stack/transpose of :256).  x_cf: (B, D, L) planes (any batch / channel stride),
+    weight (D,1,3,3), bias (D) or None  ->  u2 (B, 2*D, L) in the storage layout channel_major(B, L) picks."""
 
     @staticmethod
     def forward(ctx, x_cf, weight, bias, H, W):
         B, D, L = x_cf.shape
         assert L == H * W
-        x_cf = x_cf.float()
-        if x_cf.stride(2) != 1 or x_cf.stride(1) != L:
-            x_cf = x_cf.contiguous()
+        x_cf = _rows(x_cf)
         weight = weight.float().contiguous()
         bias = None if bias is None else bias.float().contiguous()
-        u2 = torch.empty((B, 2 * D, L), device=x_cf.device, dtype=torch.float32)
+        cm = channel_major(B, L)
+        u2 = _planes(B, 2 * D, L, x_cf.device, cm)
         with _lib.device_guard(x_cf.device):
-            rc = _lib.lib().mm_dwconv_silu_cross_fwd(x_cf.data_ptr(), x_cf.stride(0), weight.data_ptr(),
-                                                     None if bias is None else bias.data_ptr(), u2.data_ptr(),
-                                                     B, D, H, W, _stream())
+            rc = _lib.lib().mm_dwconv_silu_cross_fwd(*_pl(x_cf), weight.data_ptr(), None if bias is None else bias.data_ptr(),
+                                                     *_pl(u2), B, D, H, W, _stream())
         _lib.check(rc, "mm_dwconv_silu_cross_fwd")
         ctx.save_for_backward(x_cf, weight, bias)
         ctx.hw = (H, W)
+        ctx.cm = cm
         return u2
 
     @staticmethod
@@ -129,16 +218,16 @@ class DwConvSiluCrossFn(torch.autograd.Function):
         x_cf, weight, bias = ctx.saved_tensors
         H, W = ctx.hw
         B, D, L = x_cf.shape
-        du2 = du2.float().contiguous()
-        dx = torch.empty((B, D, L), device=du2.device, dtype=torch.float32)
+        du2 = _rows(du2)
+        dx = _planes(B, D, L, du2.device, ctx.cm)
         ws = torch.empty((B, D, 10), device=du2.device, dtype=torch.float32)
         with _lib.device_guard(du2.device):
-            rc = _lib.lib().mm_dwconv_silu_cross_bwd(du2.data_ptr(), x_cf.data_ptr(), x_cf.stride(0), weight.data_ptr(),
-                                                     None if bias is None else bias.data_ptr(), dx.data_ptr(), dx.stride(0),
-                                                     ws.data_ptr(), B, D, H, W, _stream())
+            rc = _lib.lib().mm_dwconv_silu_cross_bwd(*_pl(du2), *_pl(x_cf), weight.data_ptr(),
+                                                     None if bias is None else bias.data_ptr(), *_pl(dx), ws.data_ptr(),
+                                                     B, D, H, W, _stream())
         _lib.check(rc, "mm_dwconv_silu_cross_bwd")
         s = ws.sum(0)
-        return dx, s[:, :9].reshape(D, 1, 3, 3), (None if bias is None else s[:, 9].contiguous()), None, None
+        return dx, s[:, :9].reshape(D, 1, 3, 3), (None if bias is None else s[:, 9]), None, None
 
 
 def dwconv_silu_cross(x_cf, weight, bias, H, W):
@@ -160,9 +249,11 @@ class SS2DCoreFn(torch.autograd.Function):
     per-parameter permute / exp / zero-fill launches.  The projections live inside the Function so that autograd
     never slices x_dbl: the backward kernel writes dB / dC straight into the row blocks of d(x_dbl) (strided outputs of
     mm_scan_bwd), the dt rows are filled by one GEMM, and d(u2) collects its three contributions (two direction pairs
-    + the x projection) with one add and one GEMM (beta = 1).  Saved: u2, x_dbl, delta, the packed parameters, the
-    state checkpoints, the merged pre-norm tensor m and the LN statistics; the (B, 4D, L) scan output is freed after
-    the merge."""
+    + the x projection) with one add and one GEMM (beta = 1).  Everything the Function allocates follows
+    channel_major(B, L): in channel-major storage x_dbl is (4, C, B*L), delta (4D, B*L), and each projection (and each
+    weight gradient) is ONE GEMM; batch-major keeps the batched GEMMs + sums over B.  Saved: u2, x_dbl, delta, the packed
+    parameters, the state checkpoints, the merged pre-norm tensor m and the LN statistics; the (B, 4D, L) scan output is
+    freed after the merge."""
 
     @staticmethod
     def _segments(P, D, C, R, N):
@@ -179,86 +270,112 @@ class SS2DCoreFn(torch.autograd.Function):
         from .selective_scan_interface import _CROSS_SHARED, _launch_fwd
         Bsz, D2, L = u2.shape
         D, R, N = D2 // 2, dt_w.shape[2], A_logs.shape[1]
-        C = R + 2 * N
+        C, Q = R + 2 * N, Bsz * L
         dev = u2.device
         lib = _lib.lib()
-        u2 = u2.float().contiguous()
+        cm = channel_major(Bsz, L)
         srcs = [t.float().contiguous() for t in (x_proj_w, dt_w, dt_b, A_logs, Ds)]
         P = torch.empty((lib.mm_ss2d_pack_size(D, C, R, N),), device=dev, dtype=torch.float32)
         with _lib.device_guard(dev):
             rc = lib.mm_ss2d_pack_fwd(*[t.data_ptr() for t in srcs], P.data_ptr(), D, C, R, N, _stream())
         _lib.check(rc, "mm_ss2d_pack_fwd")
         Wx, Wdt, A, Dp, dbias = SS2DCoreFn._segments(P, D, C, R, N)
-        x_dbl = torch.matmul(Wx.view(1, 2, 2 * C, D), u2.view(Bsz, 2, D, L)).view(Bsz, 4, C, L)        # :259
-        delta = torch.matmul(Wdt.unsqueeze(0), x_dbl[:, :, :R]).view(Bsz, 4 * D, L)                    # :262
+        if cm:
+            u2m = _cm2d(_rows(u2))                                                             # (2D, Q)
+            u2 = u2m.view(2 * D, Bsz, L).permute(1, 0, 2)
+            x_dbl = torch.bmm(Wx.view(2, 2 * C, D), u2m.view(2, D, Q)).view(4, C, Q)              # :259
+            delta = torch.bmm(Wdt, x_dbl[:, :R]).view(4 * D, Bsz, L).permute(1, 0, 2)            # :262  (B, 4D, L) view
+            xb = x_dbl.view(4, C, Bsz, L).permute(2, 0, 1, 3)                                   # (B, 4, C, L) view
+        else:
+            u2 = u2.float().contiguous()
+            x_dbl = torch.matmul(Wx.view(1, 2, 2 * C, D), u2.view(Bsz, 2, D, L)).view(Bsz, 4, C, L)
+            delta = torch.matmul(Wdt.unsqueeze(0), x_dbl[:, :, :R]).view(Bsz, 4 * D, L)
+            xb = x_dbl
         need_grad = any(ctx.needs_input_grad)
-        out4, x_chk = _launch_fwd(u2, delta, A, x_dbl[:, :, R:R + N], x_dbl[:, :, R + N:], Dp, dbias, True, need_grad, 0,
+        out4, x_chk = _launch_fwd(u2, delta, A, xb[:, :, R:R + N], xb[:, :, R + N:], Dp, dbias, True, need_grad, 0,
                                   _CROSS_SHARED)
-        z_cf = z_cf.float()
-        if z_cf.stride(2) != 1 or z_cf.stride(1) != L:
-            z_cf = z_cf.contiguous()
+        z_cf = _rows(z_cf)
         ln_w, ln_b = ln_w.float().contiguous(), ln_b.float().contiguous()
-        m = torch.empty((Bsz, D, L), device=dev, dtype=torch.float32)
-        y = torch.empty((Bsz, D, L), device=dev, dtype=torch.float32)
+        m = _planes(Bsz, D, L, dev, cm)
+        y = _planes(Bsz, D, L, dev, cm)
         mu = torch.empty((Bsz, L), device=dev, dtype=torch.float32)
         rstd = torch.empty((Bsz, L), device=dev, dtype=torch.float32)
         with _lib.device_guard(dev):
-            rc = lib.mm_cross_merge_fwd(out4.data_ptr(), m.data_ptr(), Bsz, D, H, W, _stream())
+            rc = lib.mm_cross_merge_fwd(out4.data_ptr(), *_pl(m), Bsz, D, H, W, _stream())
             _lib.check(rc, "mm_cross_merge_fwd")
-            rc = lib.mm_ln_gate_fwd(m.data_ptr(), z_cf.data_ptr(), z_cf.stride(0), ln_w.data_ptr(), ln_b.data_ptr(), float(eps),
-                                    y.data_ptr(), mu.data_ptr(), rstd.data_ptr(), Bsz, D, L, _stream())
+            rc = lib.mm_ln_gate_fwd(*_pl(m), *_pl(z_cf), ln_w.data_ptr(), ln_b.data_ptr(), float(eps), *_pl(y),
+                                    mu.data_ptr(), rstd.data_ptr(), Bsz, D, L, _stream())
             _lib.check(rc, "mm_ln_gate_fwd")
         if need_grad:
             ctx.save_for_backward(u2, x_dbl, delta, P, x_chk, m, mu, rstd, z_cf, ln_w, ln_b)
-            ctx.dims = (H, W, D, C, R, N)
+            ctx.dims = (H, W, D, C, R, N, cm)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         from .selective_scan_interface import _CROSS_SHARED, _launch_bwd
         u2, x_dbl, delta, P, x_chk, m, mu, rstd, z_cf, ln_w, ln_b = ctx.saved_tensors
-        H, W, D, C, R, N = ctx.dims
+        H, W, D, C, R, N, cm = ctx.dims
         Wx, Wdt, A, Dp, dbias = SS2DCoreFn._segments(P, D, C, R, N)
         Bsz, _, L = m.shape
+        Q = Bsz * L
         dev = m.device
-        dy = dy.float().contiguous()
-        dout2 = torch.empty((Bsz, 2 * D, L), device=dev, dtype=torch.float32)    # block 0: dm, block 1: its plane transpose
-        dz = torch.empty((Bsz, D, L), device=dev, dtype=torch.float32)
+        dy = _rows(dy)
+        dout2 = _planes(Bsz, 2 * D, L, dev, cm)         # channel block 0: dm, block 1: its plane transpose
+        dz = _planes(Bsz, D, L, dev, cm)
         lib = _lib.lib()
         ws = torch.empty((lib.mm_ln_gate_rows(Bsz, L), 2 * D), device=dev, dtype=torch.float32)
         with _lib.device_guard(dev):
-            rc = lib.mm_ln_gate_bwd(dy.data_ptr(), m.data_ptr(), z_cf.data_ptr(), z_cf.stride(0), ln_w.data_ptr(), ln_b.data_ptr(),
-                                    mu.data_ptr(), rstd.data_ptr(), dout2.data_ptr(), dout2.stride(0), dz.data_ptr(),
-                                    dz.stride(0), ws.data_ptr(), Bsz, D, L, _stream())
+            rc = lib.mm_ln_gate_bwd(*_pl(dy), *_pl(m), *_pl(z_cf), ln_w.data_ptr(), ln_b.data_ptr(), mu.data_ptr(),
+                                    rstd.data_ptr(), *_pl(dout2), *_pl(dz), ws.data_ptr(), Bsz, D, L, _stream())
             _lib.check(rc, "mm_ln_gate_bwd")
-            rc = lib.mm_plane_transpose(dout2.data_ptr(), dout2.stride(0), dout2.data_ptr() + 4 * D * L, dout2.stride(0),
-                                        Bsz, D, H, W, _stream())
+            d1 = dout2[:, D:]
+            rc = lib.mm_plane_transpose(*_pl(dout2), *_pl(d1), Bsz, D, H, W, _stream())
             _lib.check(rc, "mm_plane_transpose")
         wsum = ws.sum(0)
         # gradient of the packed parameters: the A / D / bias segments are accumulated with atomics -> one zero-fill
         dP = torch.empty_like(P)
         dWx, dWdt, dA, dD, ddb = SS2DCoreFn._segments(dP, D, C, R, N)
         dP[dA.storage_offset() - dP.storage_offset():].zero_()
-        dx_dbl = torch.zeros((Bsz, 4, C, L), device=dev, dtype=torch.float32)    # dB/dC are accumulated (atomics for D > 128)
-        du4, ddelta = _launch_bwd(u2, delta, A, x_dbl[:, :, R:R + N], x_dbl[:, :, R + N:], Dp, dbias, x_chk, dout2, True,
-                                  _CROSS_SHARED, dBC=(dx_dbl[:, :, R:R + N], dx_dbl[:, :, R + N:]), dparams=(dA, dD, ddb))[:2]
-        dd = ddelta.view(Bsz, 4, D, L)
-        xr = x_dbl[:, :, :R]
-        torch.sum(torch.matmul(dd, xr.transpose(-1, -2)), 0, out=dWdt)                       # (4, D, R)
-        dx_dbl[:, :, :R] = torch.matmul(Wdt.transpose(-1, -2).unsqueeze(0), dd)               # dt rows of d(x_dbl)
-        d4 = du4.view(Bsz, 2, 2, D, L)
-        du2 = (d4[:, :, 0] + d4[:, :, 1]).view(Bsz * 2, D, L)                                 # the two directions of a pair
-        Wx2 = Wx.view(2, 2 * C, D)
-        dxd2 = dx_dbl.view(Bsz, 2, 2 * C, L)
-        du2.baddbmm_(Wx2.transpose(1, 2).unsqueeze(0).expand(Bsz, -1, -1, -1).reshape(Bsz * 2, D, 2 * C),
-                     dxd2.reshape(Bsz * 2, 2 * C, L))                                       # + Wx^T d(x_dbl)
-        torch.sum(torch.matmul(dxd2, u2.view(Bsz, 2, D, L).transpose(-1, -2)), 0, out=dWx.view(2, 2 * C, D))
+        # d(x_dbl): dB / dC rows are accumulated by the kernel (atomics when a direction spans several workgroups)
+        if cm:
+            dx_dbl = torch.zeros((4, C, Q), device=dev, dtype=torch.float32)
+            xb, dxb = x_dbl.view(4, C, Bsz, L).permute(2, 0, 1, 3), dx_dbl.view(4, C, Bsz, L).permute(2, 0, 1, 3)
+        else:
+            dx_dbl = torch.zeros((Bsz, 4, C, L), device=dev, dtype=torch.float32)
+            xb, dxb = x_dbl, dx_dbl
+        du4, ddelta = _launch_bwd(u2, delta, A, xb[:, :, R:R + N], xb[:, :, R + N:], Dp, dbias, x_chk, dout2, True,
+                                  _CROSS_SHARED, dBC=(dxb[:, :, R:R + N], dxb[:, :, R + N:]), dparams=(dA, dD, ddb),
+                                  channel_major=cm)[:2]
+        if cm:
+            dd = ddelta.permute(1, 0, 2).reshape(4, D, Q)                                      # views of (4D, B, L) storage
+            torch.bmm(dd, x_dbl[:, :R].transpose(1, 2), out=dWdt)                               # (4, D, R)
+            dx_dbl[:, :R] = torch.bmm(Wdt.transpose(1, 2), dd)                                  # dt rows of d(x_dbl)
+            d4 = du4.permute(1, 0, 2).reshape(2, 2, D, Q)
+            du2m = d4[:, 0] + d4[:, 1]                                                         # the two directions of a pair
+            dx2 = dx_dbl.view(2, 2 * C, Q)
+            du2m.baddbmm_(Wx.view(2, 2 * C, D).transpose(1, 2), dx2)                             # + Wx^T d(x_dbl)
+            torch.bmm(dx2, _cm2d(u2).view(2, D, Q).transpose(1, 2), out=dWx.view(2, 2 * C, D))
+            du2 = du2m.view(2 * D, Bsz, L).permute(1, 0, 2)
+        else:
+            dd = ddelta.view(Bsz, 4, D, L)
+            xr = x_dbl[:, :, :R]
+            torch.sum(torch.matmul(dd, xr.transpose(-1, -2)), 0, out=dWdt)                       # (4, D, R)
+            dx_dbl[:, :, :R] = torch.matmul(Wdt.transpose(-1, -2).unsqueeze(0), dd)               # dt rows of d(x_dbl)
+            d4 = du4.view(Bsz, 2, 2, D, L)
+            du2 = (d4[:, :, 0] + d4[:, :, 1]).view(Bsz * 2, D, L)                                 # the two directions of a pair
+            Wx2 = Wx.view(2, 2 * C, D)
+            dxd2 = dx_dbl.view(Bsz, 2, 2 * C, L)
+            du2.baddbmm_(Wx2.transpose(1, 2).unsqueeze(0).expand(Bsz, -1, -1, -1).reshape(Bsz * 2, D, 2 * C),
+                         dxd2.reshape(Bsz * 2, 2 * C, L))                                       # + Wx^T d(x_dbl)
+            torch.sum(torch.matmul(dxd2, u2.view(Bsz, 2, D, L).transpose(-1, -2)), 0, out=dWx.view(2, 2 * C, D))
+            du2 = du2.view(Bsz, 2 * D, L)
         G = torch.empty_like(P)
         with _lib.device_guard(dev):
             rc = lib.mm_ss2d_pack_bwd(dP.data_ptr(), P.data_ptr(), G.data_ptr(), D, C, R, N, _stream())
         _lib.check(rc, "mm_ss2d_pack_bwd")
         gWx, gWdt, gA, gD, gb = SS2DCoreFn._segments(G, D, C, R, N)
-        return (du2.view(Bsz, 2 * D, L), gWx, gWdt, gb.view(4, D), gA, gD, dz, wsum[:D], wsum[D:], None, None, None)
+        return (du2, gWx, gWdt, gb.view(4, D), gA, gD, dz, wsum[:D], wsum[D:], None, None, None)
 
 
 def ss2d_core(u2, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds, z_cf, ln_w, ln_b, H, W, eps=1e-5):

@@ -130,14 +130,23 @@ def _launch_fwd(u, delta, A, B, C, D, delta_bias, delta_softplus, want_chk, vari
     return out, x_chk
 
 
-def _launch_bwd(u, delta, A, B, C, D, delta_bias, x_chk, dout, delta_softplus, shared=(0, 0, 0), dBC=None, dparams=None):
+def _launch_bwd(u, delta, A, B, C, D, delta_bias, x_chk, dout, delta_softplus, shared=(0, 0, 0), dBC=None, dparams=None,
+                channel_major=False):
     """mm_scan_bwd on torch's current stream. Returns du (per group), ddelta, dA, dB, dC, dD, dbias.
     dBC: optional (dB_view, dC_view) — zero-filled (batch, G, N, L) views (unit stride along L) to accumulate into,
-    e.g. row blocks of the gradient of x_dbl.  dparams: optional zero-filled (dA (dim, N), dD (dim), dbias (dim))."""
+    e.g. row blocks of the gradient of x_dbl.  dparams: optional zero-filled (dA (dim, N), dD (dim), dbias (dim)).
+    channel_major: du / ddelta are returned as (batch, dim, L) views of (dim, batch, L) storage; dout must then have the
+    same channel stride (batch * L)."""
     batch, dim, L = delta.shape
     G, N = B.shape[1], A.shape[1]
     dev = u.device
-    du, ddelta = torch.empty_like(delta), torch.empty_like(delta)
+    if channel_major:
+        du = torch.empty((dim, batch, L), device=dev, dtype=torch.float32).permute(1, 0, 2)
+        ddelta = torch.empty((dim, batch, L), device=dev, dtype=torch.float32).permute(1, 0, 2)
+    else:
+        du = torch.empty((batch, dim, L), device=dev, dtype=torch.float32)
+        ddelta = torch.empty((batch, dim, L), device=dev, dtype=torch.float32)
+    assert dout.stride(2) == 1 and dout.stride(1) == du.stride(1), "dout and du/ddelta must share the channel stride"
     # accumulated with atomics across batch / channel tiles -> zero-filled here (header contract)
     if dparams is None:
         dA = torch.zeros((dim, N), device=dev, dtype=torch.float32)
@@ -158,6 +167,7 @@ def _launch_bwd(u, delta, A, B, C, D, delta_bias, x_chk, dout, delta_softplus, s
     a.du, a.ddelta, a.dA, a.dB, a.dC = du.data_ptr(), ddelta.data_ptr(), dA.data_ptr(), dB.data_ptr(), dC.data_ptr()
     a.dD, a.ddelta_bias = _ptr(dD), _ptr(dbias)
     a.u_groups, a.u_map, a.rev_mask = shared
+    a.dout_sb, a.dud_sb, a.o_sd = dout.stride(0), du.stride(0), du.stride(1)
     a.variant = _BWD_VARIANT
     if dBC is not None:
         a.dB_sb, a.dB_sg, a.dB_sn = dB.stride(0), dB.stride(1), dB.stride(2)

@@ -28,14 +28,14 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(h, name), name
         assert name in _lib.SYMBOLS, f"{name} declared in the header but not bound in _lib.SYMBOLS"
     assert set(_lib.SYMBOLS) <= set(decl)
-    assert _lib.lib().mm_abi_version() == 5
+    assert _lib.lib().mm_abi_version() == 6
     assert _lib.scan_chunk() == 16
     assert b"unsupported" in _lib.lib().mm_status_string(-3)
 
 
 def test_struct_layout_matches_header():
-    # 6 int32 + 9 pointers + 10 int64 + 8 pointers + 4 int32 + 6 int64 (LP64)
-    assert ctypes.sizeof(_lib.ScanArgs) == 6 * 4 + 9 * 8 + 10 * 8 + 8 * 8 + 4 * 4 + 6 * 8
+    # 6 int32 + 9 pointers + 10 int64 + 8 pointers + 4 int32 + 9 int64 (LP64)
+    assert ctypes.sizeof(_lib.ScanArgs) == 6 * 4 + 9 * 8 + 10 * 8 + 8 * 8 + 4 * 4 + 9 * 8
 
 
 def test_bad_arguments_are_rejected_without_launch():

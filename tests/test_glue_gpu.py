@@ -8,6 +8,19 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
+@pytest.fixture(params=["bm", "cm"])
+def layout(request, monkeypatch):
+    """Run the plane ops in both storage layouts (batch-major / channel-major planes; ops.channel_major)."""
+    from medmamba_amd import ops
+    monkeypatch.setattr(ops, "_LAYOUT", request.param)
+    return request.param
+
+
+def _cm(t):
+    """Same values as (B, D, L) tensor t, stored channel-major (D, B, L)."""
+    return t.permute(1, 0, 2).contiguous().permute(1, 0, 2)
+
+
 @pytest.mark.parametrize("shape", [(2, 8, 6, 5), (1, 48, 56, 56), (3, 33, 7, 9), (2, 64, 4, 4)])
 def test_shuffle_residual_forward_backward(shape):
     from medmamba_amd.ops import shuffle_residual
@@ -35,6 +48,13 @@ def test_shuffle_residual_forward_backward(shape):
     assert torch.equal(out_cf.detach().cpu(), ref.detach())
     assert torch.equal(dev_cf[1].grad.cpu(), ref_in[1].grad.reshape(B, H * W, C2).transpose(1, 2))
     assert torch.equal(dev_cf[0].grad.cpu(), ref_in[0].grad)
+    # ... and the same planes stored channel-major (C/2, B, H*W)
+    leaf = ssm_cf.to(DEV).requires_grad_()
+    dev_cm = [left.to(DEV).requires_grad_(), leaf, inp.to(DEV).requires_grad_()]
+    out_cm = shuffle_residual(dev_cm[0], _cm(leaf), dev_cm[2], channel_first=True)
+    out_cm.backward(dout.to(DEV))
+    assert torch.equal(out_cm.detach().cpu(), ref.detach())
+    assert torch.equal(leaf.grad.cpu(), ref_in[1].grad.reshape(B, H * W, C2).transpose(1, 2))
     # folded neighbours: trailing ReLU of the conv branch + per-sample DropPath factor (MedMamba.py:347, 353)
     scale = (torch.rand(B, generator=g) > 0.4).float() / 0.6
     for cf in (False, True):
@@ -51,7 +71,7 @@ def test_shuffle_residual_forward_backward(shape):
         assert torch.equal(dev_in[2].grad.cpu(), ref_in[2].grad)
 
 
-def test_in_proj_cf_forward_backward():
+def test_in_proj_cf_forward_backward(layout):
     from medmamba_amd.ops import in_proj_cf
     from oracle.model_ref import in_proj_cf_ref
     g = torch.Generator().manual_seed(3)
@@ -64,7 +84,9 @@ def test_in_proj_cf_forward_backward():
         torch.autograd.backward([a0, b0], [gx, gz])
         d = [t.to(DEV).requires_grad_() for t in (x, w, bias)]
         a1, b1 = in_proj_cf(d[0], d[1], d[2] if use_bias else None)
-        torch.autograd.backward([a1, b1], [gx.to(DEV), gz.to(DEV)])
+        assert a1.shape == (B, D, L) and b1.shape == (B, D, L)
+        gg = [gx.to(DEV), gz.to(DEV)]
+        torch.autograd.backward([a1, b1], [_cm(t) for t in gg] if layout == "cm" else gg)
         close = lambda p, q: (p.detach().cpu() - q.detach()).abs().max().item() <= 2e-5 * max(1.0, q.detach().abs().max().item())
         assert close(a1, a0) and close(b1, b0)
         for p, q in list(zip(d, r))[: 3 if use_bias else 2]:
@@ -72,7 +94,7 @@ def test_in_proj_cf_forward_backward():
 
 
 @pytest.mark.parametrize("shape", [(2, 8, 5, 7), (1, 96, 56, 56), (2, 16, 14, 14), (3, 5, 7, 7), (1, 4, 33, 40)])
-def test_dwconv_silu_cross_forward_backward(shape):
+def test_dwconv_silu_cross_forward_backward(shape, layout):
     from medmamba_amd.ops import dwconv_silu_cross
     from oracle.model_ref import dwconv_silu_cross_ref
     B, D, H, W = shape
@@ -86,7 +108,7 @@ def test_dwconv_silu_cross_forward_backward(shape):
     ref.backward(du2)
     xd, wd, bd = xz.to(DEV).requires_grad_(), w.to(DEV).requires_grad_(), bias.to(DEV).requires_grad_()
     out = dwconv_silu_cross(xd[:, :D], wd, bd, H, W)
-    out.backward(du2.to(DEV))
+    out.backward(_cm(du2.to(DEV)) if layout == "cm" else du2.to(DEV))
     close = lambda a, b, tol: (a.detach().cpu() - b.detach()).abs().max().item() <= tol * max(1.0, b.detach().abs().max().item())
     assert close(out, ref, 2e-6)
     assert close(xd.grad, xr.grad, 1e-5)
@@ -95,7 +117,7 @@ def test_dwconv_silu_cross_forward_backward(shape):
 
 
 @pytest.mark.parametrize("shape", [(2, 8, 5, 7, 1), (1, 24, 14, 14, 2), (2, 16, 9, 4, 3), (1, 8, 33, 36, 1), (1, 160, 6, 6, 5)])
-def test_ss2d_core_forward_backward(shape):
+def test_ss2d_core_forward_backward(shape, layout):
     """projections + scan + cross-merge + out_norm + gate (channel-first HIP path) vs the oracle chain (einsums, explicit
     flips, torch LN).  The last shape has D > 128: a direction is split over several backward workgroups (atomics)."""
     from medmamba_amd.ops import ss2d_core
@@ -115,8 +137,12 @@ def test_ss2d_core_forward_backward(shape):
     ref = ss2d_core_ref(*ref_in, H, W, 1e-5)
     ref.backward(dy)
     dev_in = [t.to(DEV).requires_grad_() for t in leaves]
-    out = ss2d_core(*dev_in, H, W, 1e-5)
-    out.backward(dy.to(DEV))
+    if layout == "cm":      # inputs as the neighbouring ops hand them over in this layout; u2 / z stay the autograd leaves
+        out = ss2d_core(_cm(dev_in[0]), *dev_in[1:6], _cm(dev_in[6]), *dev_in[7:], H, W, 1e-5)
+        out.backward(_cm(dy.to(DEV)))
+    else:
+        out = ss2d_core(*dev_in, H, W, 1e-5)
+        out.backward(dy.to(DEV))
     err = (out.detach().cpu() - ref.detach()).abs().max().item()
     assert err <= 5e-5 * max(1.0, ref.detach().abs().max().item()), err
     names = ["du2", "dWx", "dWdt", "dbias", "dA_logs", "dD", "dz", "dln_w", "dln_b"]

@@ -117,3 +117,33 @@ def test_two_stream_blocks_match_single_stream(monkeypatch):
         for k in g0:
             scale = max(1e-4, float(g0[k].abs().max()))
             assert float((g0[k] - g[k]).abs().max()) <= 2e-3 * scale, (it, two, k)
+
+
+@pytest.mark.parametrize("layout", ["bm", "cm"])
+def test_block_and_tiny_model_in_both_plane_layouts(layout, monkeypatch):
+    """SS_Conv_SSM and the tiny VSSM, fwd + bwd, with the SS2D planes forced batch-major / channel-major
+    (ops.channel_major) against the committed reference fixtures — the storage layout must not change any value."""
+    from medmamba_amd import modules, ops
+    monkeypatch.setattr(ops, "_LAYOUT", layout)
+    fx = load_golden("block_c16.npz")
+    blk = modules.SS_Conv_SSM(hidden_dim=16, drop_path=0.0, norm_layer=torch.nn.LayerNorm)
+    blk.load_state_dict(split_sd(fx))
+    blk.to(DEV).train()
+    x = torch.from_numpy(fx["x"]).to(DEV).requires_grad_()
+    y = blk(x)
+    _close(y, fx["y_train"], 1e-4, "y_train")
+    y.backward(torch.from_numpy(fx["dy"]).to(DEV))
+    _close(x.grad, fx["dx"], 5e-4, "dx")
+    for k, p in blk.named_parameters():
+        _close(p.grad, fx["grad/" + k], 2e-3, k)
+    fx = load_golden("vssm_tiny.npz")
+    net = modules.VSSM(num_classes=3, depths=[int(v) for v in fx["depths"]], dims=[int(v) for v in fx["dims"]],
+                       drop_path_rate=0.0)
+    net.load_state_dict(split_sd(fx))
+    net.to(DEV).train()
+    logits = net(torch.from_numpy(fx["x"]).to(DEV))
+    _close(logits, fx["logits_train"], 2e-4, "logits_train")
+    torch.nn.functional.cross_entropy(logits, torch.from_numpy(fx["labels"]).to(DEV)).backward()
+    worst = max(np.abs(p.grad.cpu().numpy() - fx["grad/" + k]).max() / max(1e-3, np.abs(fx["grad/" + k]).max())
+                for k, p in net.named_parameters())
+    assert worst <= 5e-3, worst
