@@ -125,7 +125,9 @@ def main():
     torch.manual_seed(42)                      # identical replicas; random-init weights (no checkpoints offline)
     net = VSSM(num_classes=6, **MEDMAMBA_CONFIGS[args.size]).to(dev).train()
     model = wrap_ddp(net, dev) if world > 1 else net
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=1e-4)     # train.py:189-192 (ImageFolder branch)
+    # train.py:189-192 (ImageFolder branch); fused=True: same update rule, one multi-tensor kernel per step
+    okw = {"fused": True} if os.environ.get("MM_FUSED_ADAMW", "1") == "1" else {}      # else: torch's default (foreach)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=1e-4, **okw)
     loss_fn = nn.CrossEntropyLoss()
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     images = torch.randn(args.batch, 3, args.res, args.res, device=dev, generator=g)   # resident in HBM
