@@ -122,6 +122,8 @@ def main():
     from medmamba_amd.selective_scan_interface import KERNEL_TIMER
     from medmamba_amd.ddp import wrap_ddp
 
+    if os.environ.get("MM_MIOPEN_BENCHMARK", "0") == "1":
+        torch.backends.cudnn.benchmark = True      # MIOpen times its solvers per conv shape during the warm-up steps
     torch.manual_seed(42)                      # identical replicas; random-init weights (no checkpoints offline)
     net = VSSM(num_classes=6, **MEDMAMBA_CONFIGS[args.size]).to(dev).train()
     model = wrap_ddp(net, dev) if world > 1 else net

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MM_ABI_VERSION 6
+#define MM_ABI_VERSION 7
 
 enum mm_status {
   MM_OK = 0,
@@ -172,12 +172,13 @@ int mm_ln_gate_rows(int batch, int L);
 /* Block prologue of SS_Conv_SSM.forward (MedMamba.py:350-352): inp (batch, P, 2*C2) NHWC ->
  *   left_nchw (batch, C2, P) = inp[..., :C2] transposed (conv-branch input, replaces chunk + permute + contiguous)
  *   rn (batch, P, C2) = LayerNorm_{C2}(inp[..., C2:]) * gamma + beta  (ln_1), statistics mu/rstd (batch*P).
- * Backward writes BOTH halves of dinp (batch, P, 2*C2) — left from dleft_nchw, right from drn — and per-wave partial
+ * Backward writes BOTH halves of dinp (batch, P, 2*C2) — left from dleft_nchw, right from drn, plus dres (batch, P, 2*C2)
+ * or NULL: the gradient that reaches the block input through the residual add of MedMamba.py:357 — and per-wave partial
  * sums ws[row*2*C2 + (0: dgamma, C2: dbeta) + c], row < mm_block_split_rows(batch, P, C2) (the caller sums rows). */
 int mm_block_split_fwd(const float* inp, const float* gamma, const float* beta, float eps, float* left_nchw, float* rn,
                        float* mu, float* rstd, int batch, int P, int C2, void* stream);
-int mm_block_split_bwd(const float* dleft_nchw, const float* drn, const float* inp, const float* gamma, const float* mu,
-                       const float* rstd, float* dinp, float* ws, int batch, int P, int C2, void* stream);
+int mm_block_split_bwd(const float* dleft_nchw, const float* drn, const float* dres, const float* inp, const float* gamma,
+                       const float* mu, const float* rstd, float* dinp, float* ws, int batch, int P, int C2, void* stream);
 int mm_block_split_rows(int batch, int P, int C2);
 
 /* SS2D parameters (MedMamba.py:150-175) -> one buffer in kernel direction order, A = -exp(A_logs) (MedMamba.py:271):

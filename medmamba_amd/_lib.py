@@ -56,7 +56,7 @@ SYMBOLS = {
     "mm_ln_gate_rows": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
     "mm_block_split_fwd": (ctypes.c_int, [_f32p, _f32p, _f32p, ctypes.c_float, _f32p, _f32p, _f32p, _f32p] + [ctypes.c_int] * 3
                            + [ctypes.c_void_p]),
-    "mm_block_split_bwd": (ctypes.c_int, [_f32p] * 8 + [ctypes.c_int] * 3 + [ctypes.c_void_p]),
+    "mm_block_split_bwd": (ctypes.c_int, [_f32p] * 9 + [ctypes.c_int] * 3 + [ctypes.c_void_p]),
     "mm_block_split_rows": (ctypes.c_int, [ctypes.c_int] * 3),
     "mm_shuffle_residual_bwd": (ctypes.c_int, [_f32p, _f32p, _f32p, _i64, _i64, _f32p, _f32p] + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
     "mm_ss2d_pack_size": (ctypes.c_int, [ctypes.c_int] * 4),
@@ -86,7 +86,7 @@ def lib():
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(handle, name)      # AttributeError if the .so is stale
             fn.restype, fn.argtypes = res, args
-        if handle.mm_abi_version() != 6:
+        if handle.mm_abi_version() != 7:
             raise MedMambaHipError("libmedmamba_hip.so ABI version mismatch; rebuild")
         _lib = handle
     return _lib

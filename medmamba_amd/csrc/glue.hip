@@ -287,7 +287,6 @@ __global__ __launch_bounds__(256) void plane_transpose_kernel(const float* __res
   const int nbw = (W + 31) / 32, nbh = (H + 31) / 32;
   const int w0 = (blockIdx.x % nbw) * 32, h0 = ((blockIdx.x / nbw) % nbh) * 32, pl = blockIdx.x / (nbw * nbh);
   const int b = pl / D, d = pl % D;
-  const int64_t L = (int64_t)H * W;
   const float* s = src + (int64_t)b * src_sb + (int64_t)d * src_sd;
   float* t = dst + (int64_t)b * dst_sb + (int64_t)d * dst_sd;
 #pragma unroll
@@ -572,8 +571,9 @@ __global__ __launch_bounds__(256) void ln_half_fwd_kernel(const float* __restric
 template <int TPR>
 __global__ __launch_bounds__(256) void ln_half_bwd_kernel(const float* __restrict__ drn, const float* __restrict__ inp,
                                                           const float* __restrict__ gamma, const float* __restrict__ mu_in,
-                                                          const float* __restrict__ rstd_in, float* __restrict__ dinp,
-                                                          float* __restrict__ ws, int64_t nrows, int C, int C2) {
+                                                          const float* __restrict__ rstd_in, const float* __restrict__ dres,
+                                                          float* __restrict__ dinp, float* __restrict__ ws, int64_t nrows, int C,
+                                                          int C2) {
   constexpr int RPW = 64 / TPR;
   const int lane = threadIdx.x & 63, lr = lane % TPR;
   const int64_t wave_global = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
@@ -605,7 +605,7 @@ __global__ __launch_bounds__(256) void ln_half_bwd_kernel(const float* __restric
 #pragma unroll
       for (int k = 0; k < kLnNV; ++k) {
         const int c = lr + k * TPR;
-        if (c < C2) dinp[row * C + C2 + c] = rstd * (g[k] - c1 - xh[k] * c2);
+        if (c < C2) dinp[row * C + C2 + c] = rstd * (g[k] - c1 - xh[k] * c2) + (dres ? dres[row * C + C2 + c] : 0.f);
       }
     }
   }
@@ -625,9 +625,10 @@ __global__ __launch_bounds__(256) void ln_half_bwd_kernel(const float* __restric
 
 // dst[b, i, p] = src[b, p, i] for i < C2 (src row stride C): NHWC half -> NCHW.  REV: the other way round
 // (dst[b, p, i] = src[b, i, p] written into a buffer with row stride C).  grid: ceil(P/32) * ceil(C2/32) * batch
+// REV only: `add` (same layout as dst, or null) is added to what is written (gradient of the residual path).
 template <bool REV>
-__global__ __launch_bounds__(256) void half_transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int P, int C,
-                                                             int C2) {
+__global__ __launch_bounds__(256) void half_transpose_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                             const float* __restrict__ add, int P, int C, int C2) {
   __shared__ float tile[32][33];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const int nbp = (P + 31) / 32, nbi = (C2 + 31) / 32;
@@ -655,10 +656,11 @@ __global__ __launch_bounds__(256) void half_transpose_kernel(const float* __rest
     }
     __syncthreads();
     float* d = dst + (int64_t)b * P * C;
+    const float* a = add ? add + (int64_t)b * P * C : nullptr;
 #pragma unroll
     for (int r = ty; r < 32; r += 8) {
       const int p = p0 + r, i = i0 + tx;
-      if (p < P && i < C2) d[(int64_t)p * C + i] = tile[tx][r];
+      if (p < P && i < C2) d[(int64_t)p * C + i] = tile[tx][r] + (a ? a[(int64_t)p * C + i] : 0.f);
     }
   }
 }
@@ -685,23 +687,23 @@ int mm_block_split_fwd(const float* inp, const float* gamma, const float* beta, 
   hipStream_t s = (hipStream_t)stream;
   const int C = 2 * C2;
   const int64_t nrows = (int64_t)batch * P;
-  hipLaunchKernelGGL(half_transpose_kernel<false>, dim3(((P + 31) / 32) * ((C2 + 31) / 32) * batch), dim3(256), 0, s, inp, left_nchw, P, C, C2);
+  hipLaunchKernelGGL(half_transpose_kernel<false>, dim3(((P + 31) / 32) * ((C2 + 31) / 32) * batch), dim3(256), 0, s, inp, left_nchw, nullptr, P, C, C2);
   if (C2 <= 128) hipLaunchKernelGGL(ln_half_fwd_kernel<16>, dim3(ln_half_grid(nrows, 16)), dim3(256), 0, s, inp, gamma, beta, eps, rn, mu, rstd, nrows, C, C2);
   else hipLaunchKernelGGL(ln_half_fwd_kernel<64>, dim3(ln_half_grid(nrows, 64)), dim3(256), 0, s, inp, gamma, beta, eps, rn, mu, rstd, nrows, C, C2);
   return (int)hipGetLastError();
 }
 
-int mm_block_split_bwd(const float* dleft_nchw, const float* drn, const float* inp, const float* gamma, const float* mu,
-                       const float* rstd, float* dinp, float* ws, int batch, int P, int C2, void* stream) {
+int mm_block_split_bwd(const float* dleft_nchw, const float* drn, const float* dres, const float* inp, const float* gamma,
+                       const float* mu, const float* rstd, float* dinp, float* ws, int batch, int P, int C2, void* stream) {
   if (!dleft_nchw || !drn || !inp || !gamma || !mu || !rstd || !dinp || !ws) return MM_ERR_NULL;
   if (batch <= 0 || P <= 0 || C2 <= 0) return MM_ERR_SHAPE;
   if (C2 > 8 * 64) return MM_ERR_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   const int C = 2 * C2;
   const int64_t nrows = (int64_t)batch * P;
-  hipLaunchKernelGGL(half_transpose_kernel<true>, dim3(((P + 31) / 32) * ((C2 + 31) / 32) * batch), dim3(256), 0, s, dleft_nchw, dinp, P, C, C2);
-  if (C2 <= 128) hipLaunchKernelGGL(ln_half_bwd_kernel<16>, dim3(ln_half_grid(nrows, 16)), dim3(256), 0, s, drn, inp, gamma, mu, rstd, dinp, ws, nrows, C, C2);
-  else hipLaunchKernelGGL(ln_half_bwd_kernel<64>, dim3(ln_half_grid(nrows, 64)), dim3(256), 0, s, drn, inp, gamma, mu, rstd, dinp, ws, nrows, C, C2);
+  hipLaunchKernelGGL(half_transpose_kernel<true>, dim3(((P + 31) / 32) * ((C2 + 31) / 32) * batch), dim3(256), 0, s, dleft_nchw, dinp, dres, P, C, C2);
+  if (C2 <= 128) hipLaunchKernelGGL(ln_half_bwd_kernel<16>, dim3(ln_half_grid(nrows, 16)), dim3(256), 0, s, drn, inp, gamma, mu, rstd, dres, dinp, ws, nrows, C, C2);
+  else hipLaunchKernelGGL(ln_half_bwd_kernel<64>, dim3(ln_half_grid(nrows, 64)), dim3(256), 0, s, drn, inp, gamma, mu, rstd, dres, dinp, ws, nrows, C, C2);
   return (int)hipGetLastError();
 }
 

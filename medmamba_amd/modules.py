@@ -292,7 +292,7 @@ class SS_Conv_SSM(nn.Module):
     def forward(self, input):
         if isinstance(self.ln_1, nn.LayerNorm) and self.ln_1.elementwise_affine and self.ln_1.bias is not None:
             # chunk + permute(0,3,1,2).contiguous() + ln_1 (MedMamba.py:350-352) in one fused HIP prologue
-            left, right_n = block_split(input, self.ln_1.weight, self.ln_1.bias, self.ln_1.eps)
+            left, right_n, input = block_split(input, self.ln_1.weight, self.ln_1.bias, self.ln_1.eps)
         else:                                                  # any other norm_layer: the reference's own op chain
             left, right = input.chunk(2, dim=-1)
             left, right_n = left.permute(0, 3, 1, 2).contiguous(), self.ln_1(right)

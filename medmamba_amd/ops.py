@@ -390,8 +390,10 @@ def ss2d_core(u2, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds, z_c
 
 
 class BlockSplitFn(torch.autograd.Function):
-    """SS_Conv_SSM prologue (MedMamba.py:350-352): inp (B,H,W,C) -> (left NCHW (B,C/2,H,W), LayerNorm(right) (B,H,W,C/2)).
-    The backward writes both halves of d(inp) in place — no chunk/cat copies, no strided-LayerNorm copy."""
+    """SS_Conv_SSM prologue (MedMamba.py:350-352): inp (B,H,W,C) -> (left NCHW (B,C/2,H,W), LayerNorm(right) (B,H,W,C/2),
+    inp itself for the residual add of :357).  The backward writes both halves of d(inp) in place — no chunk/cat copies,
+    no strided-LayerNorm copy — and adds the gradient that arrives through the residual output in the same pass, so
+    autograd never has to sum two gradients of the block input."""
 
     @staticmethod
     def forward(ctx, inp, gamma, beta, eps):
@@ -409,27 +411,31 @@ class BlockSplitFn(torch.autograd.Function):
                                                rn.data_ptr(), mu.data_ptr(), rstd.data_ptr(), B, P, C2, _stream())
         _lib.check(rc, "mm_block_split_fwd")
         ctx.save_for_backward(inp, gamma, mu, rstd)
-        return left, rn
+        return left, rn, inp.view_as(inp)
 
     @staticmethod
-    def backward(ctx, dleft, drn):
+    def backward(ctx, dleft, drn, dres):
         inp, gamma, mu, rstd = ctx.saved_tensors
         B, H, W, C = inp.shape
         C2, P = C // 2, H * W
         dev = inp.device
         dleft, drn = dleft.float().contiguous(), drn.float().contiguous()
+        dres = None if dres is None else dres.float().contiguous()
         dinp = torch.empty_like(inp)
         lib = _lib.lib()
         ws = torch.empty((lib.mm_block_split_rows(B, P, C2), 2 * C2), device=dev, dtype=torch.float32)
         with _lib.device_guard(dev):
-            rc = lib.mm_block_split_bwd(dleft.data_ptr(), drn.data_ptr(), inp.data_ptr(), gamma.data_ptr(), mu.data_ptr(),
-                                        rstd.data_ptr(), dinp.data_ptr(), ws.data_ptr(), B, P, C2, _stream())
+            rc = lib.mm_block_split_bwd(dleft.data_ptr(), drn.data_ptr(), None if dres is None else dres.data_ptr(),
+                                        inp.data_ptr(), gamma.data_ptr(), mu.data_ptr(), rstd.data_ptr(), dinp.data_ptr(),
+                                        ws.data_ptr(), B, P, C2, _stream())
         _lib.check(rc, "mm_block_split_bwd")
         s = ws.sum(0)
-        return dinp, s[:C2].contiguous(), s[C2:].contiguous(), None
+        return dinp, s[:C2], s[C2:], None
 
 
 def block_split(inp, gamma, beta, eps):
+    """-> (left NCHW, LayerNorm(right) NHWC, inp for the residual add — use THIS alias as the residual input so that its
+    gradient is folded into the backward kernel)."""
     _need_hip(inp)
     if inp.shape[-1] % 2 or inp.shape[-1] // 2 > 512:
         raise NotImplementedError("block_split: even channel count <= 1024 expected")

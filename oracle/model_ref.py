@@ -203,4 +203,4 @@ def ss2d_core_ref(u2, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds,
 def block_split_ref(inp, gamma, beta, eps):
     """Test double for medmamba_amd.ops.block_split: chunk + permute + ln_1 exactly as MedMamba.py:350-352."""
     left, right = inp.chunk(2, dim=-1)
-    return left.permute(0, 3, 1, 2).contiguous(), F.layer_norm(right, (right.shape[-1],), gamma, beta, eps)
+    return left.permute(0, 3, 1, 2).contiguous(), F.layer_norm(right, (right.shape[-1],), gamma, beta, eps), inp

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(h, name), name
         assert name in _lib.SYMBOLS, f"{name} declared in the header but not bound in _lib.SYMBOLS"
     assert set(_lib.SYMBOLS) <= set(decl)
-    assert _lib.lib().mm_abi_version() == 6
+    assert _lib.lib().mm_abi_version() == 7
     assert _lib.scan_chunk() == 16
     assert b"unsupported" in _lib.lib().mm_status_string(-3)
 

@@ -161,14 +161,23 @@ def test_block_split_forward_backward(shape):
     gamma, beta = 1 + 0.2 * torch.randn(C // 2, generator=g), 0.2 * torch.randn(C // 2, generator=g)
     dl, dr = torch.randn(B, C // 2, H, W, generator=g), torch.randn(B, H, W, C // 2, generator=g)
     ri, rg_, rb = inp.clone().requires_grad_(), gamma.clone().requires_grad_(), beta.clone().requires_grad_()
-    l0, r0 = block_split_ref(ri, rg_, rb, 1e-5)
-    torch.autograd.backward([l0, r0], [dl, dr])
+    dres = torch.randn(B, H, W, C, generator=g)             # gradient arriving through the residual alias of inp
+    l0, r0, i0 = block_split_ref(ri, rg_, rb, 1e-5)
+    torch.autograd.backward([l0, r0, i0], [dl, dr, dres])
     di, dg, db = inp.to(DEV).requires_grad_(), gamma.to(DEV).requires_grad_(), beta.to(DEV).requires_grad_()
-    l1, r1 = block_split(di, dg, db, 1e-5)
-    torch.autograd.backward([l1, r1], [dl.to(DEV), dr.to(DEV)])
-    assert torch.equal(l1.detach().cpu(), l0.detach())
+    l1, r1, i1 = block_split(di, dg, db, 1e-5)
+    torch.autograd.backward([l1, r1, i1], [dl.to(DEV), dr.to(DEV), dres.to(DEV)])
+    assert torch.equal(l1.detach().cpu(), l0.detach()) and torch.equal(i1.detach().cpu(), inp)
     close = lambda a, b, tol: (a.detach().cpu() - b.detach()).abs().max().item() <= tol * max(1.0, b.detach().abs().max().item())
     assert close(r1, r0, 5e-6)
     assert close(di.grad, ri.grad, 2e-5)
     assert close(dg.grad, rg_.grad, 5e-5)
     assert close(db.grad, rb.grad, 5e-5)
+    # residual alias unused -> no residual gradient (NULL) path
+    di2 = inp.to(DEV).requires_grad_()
+    l2, r2, _ = block_split(di2, dg.detach(), db.detach(), 1e-5)
+    torch.autograd.backward([l2, r2], [dl.to(DEV), dr.to(DEV)])
+    ri2 = inp.clone().requires_grad_()
+    l3, r3, _ = block_split_ref(ri2, gamma, beta, 1e-5)
+    torch.autograd.backward([l3, r3], [dl, dr])
+    assert close(di2.grad, ri2.grad, 2e-5)

@@ -11,10 +11,12 @@ dev = torch.device("cuda:0")
 blk = SS_Conv_SSM(hidden_dim=dim, drop_path=0.0, norm_layer=torch.nn.LayerNorm).to(dev).train()
 x = torch.randn(B, hw, hw, dim, device=dev, requires_grad=True)
 for _ in range(3):
+    blk.zero_grad(set_to_none=True); x.grad = None
     blk(x).sum().backward()
 torch.cuda.synchronize()
 from torch.profiler import profile, ProfilerActivity
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+    blk.zero_grad(set_to_none=True); x.grad = None
     y = blk(x); y.backward(torch.ones_like(y)); torch.cuda.synchronize()
 rows = [e for e in prof.key_averages(group_by_input_shape=True)
         if e.key in ("aten::copy_", "aten::fill_", "aten::zero_", "aten::add", "aten::add_", "aten::sum", "aten::mul", "aten::cat", "aten::stack", "aten::exp", "aten::neg")]
