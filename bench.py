@@ -14,6 +14,9 @@ over RCCL (backend "nccl").  Rank 0 prints ONE JSON line.
 Extra objects on the line:
   roofline     — the selective-scan forward kernel (the north-star kernel): algorithmic bytes
                  of every forward scan call in the timed steps / their hipEvent-measured duration, vs 8 TB/s.
+                 In the timed steps the conv branch of every block runs beside the scan on a second HIP stream, so
+                 `achieved` is the kernel's rate while sharing the GPU; `achieved_alone` / `frac_alone` repeat the
+                 measurement in 3 extra untimed steps with that overlap switched off (N=1 only).
   roofline_bwd — same for the backward scan kernel.
   cpu_baseline — the CPU restatement of the reference path (oracle/: torch-CPU glue + C selective_scan_ref)
                  timed on this box's host cores on a bounded sample (rank 0, N=1 only).
@@ -98,6 +101,8 @@ def main():
     ap.add_argument("--res", type=int, default=224)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse)")
+    ap.add_argument("--no-alone-pass", action="store_true", help="skip the 3 untimed steps that re-measure the scan kernels "
+                    "without the side-stream overlap (use under rocprofv3 so that the trace holds overlapped steps only)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
     args = ap.parse_args()
 
@@ -159,6 +164,22 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     KERNEL_TIMER.enabled = False
+    ks = KERNEL_TIMER.summary() if rank == 0 else {}
+    ks_iso = {}
+    if rank == 0 and world == 1 and not args.no_alone_pass:
+        # untimed extra pass: the same kernels on the same shapes WITHOUT the conv branch running beside them on the
+        # side stream (modules._TWO_STREAMS) — the kernel's own rate, next to the rate it gets inside the overlapped step
+        from medmamba_amd import modules as _modules
+        two = _modules._TWO_STREAMS
+        _modules._TWO_STREAMS = False
+        KERNEL_TIMER.records.clear()
+        KERNEL_TIMER.enabled = True
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        KERNEL_TIMER.enabled = False
+        _modules._TWO_STREAMS = two
+        ks_iso = KERNEL_TIMER.summary()
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -166,8 +187,6 @@ def main():
     assert torch.isfinite(loss).item(), "loss is not finite"
 
     if rank == 0:
-        ks = KERNEL_TIMER.summary()
-
         try:      # PMC-derived HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/scan_traffic.json)
             traffic = json.load(open(os.path.join(ROOT, "profiles", "scan_traffic.json")))
         except Exception:
@@ -181,10 +200,15 @@ def main():
             gbs = d["bytes"] / d["ms"] / 1e6
             tr = traffic.get(tag, {}).get("bytes_per_launch") if std_workload else None
             tr = None if tr is None else round(tr * d["calls"] / d["ms"] / 1e6, 1)      # GB/s, same basis as `achieved`
-            return {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": tr, "kernel": tag,
-                    "calls": d["calls"], "avg_us_per_call": round(1e3 * d["ms"] / d["calls"], 2),
-                    "algorithmic_MB_per_call": round(d["bytes"] / d["calls"] / 1e6, 2)}
+            r = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                 "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": tr, "kernel": tag,
+                 "calls": d["calls"], "avg_us_per_call": round(1e3 * d["ms"] / d["calls"], 2),
+                 "algorithmic_MB_per_call": round(d["bytes"] / d["calls"] / 1e6, 2)}
+            i = ks_iso.get(tag)
+            if i and i["ms"] > 0:       # same kernel, same shapes, nothing else on the GPU (see above)
+                r["achieved_alone"] = round(i["bytes"] / i["ms"] / 1e6, 1)
+                r["frac_alone"] = round(r["achieved_alone"] / HBM_PEAK_GBS, 4)
+            return r
 
         out = {
             "metric": "images/sec fwd+bwd MedMamba-S 224^2", "value": round(args.batch * world * args.steps / dt, 2),
