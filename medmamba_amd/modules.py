@@ -33,6 +33,20 @@ _TWO_STREAMS = __import__("os").environ.get("MM_TWO_STREAMS", "1") == "1"   # MM
 _SIDE_STREAMS = {}
 
 
+def _has_hooks(module):
+    """True if `module` or anything below it carries a forward / backward hook (or a global module hook is installed).
+    The fused paths below reach past sub-modules' __call__ (they read .weight / .bias directly); code that hangs hooks on
+    sub-modules — e.g. Grad-CAM on `conv33conv33conv11[-2]` (test.py:101-108) — gets the module-by-module path instead."""
+    import torch.nn.modules.module as _m
+    if (_m._global_forward_hooks or _m._global_forward_pre_hooks or _m._global_backward_hooks
+            or _m._global_backward_pre_hooks):
+        return True
+    for sub in module.modules():
+        if sub._forward_hooks or sub._forward_pre_hooks or sub._backward_hooks or sub._backward_pre_hooks:
+            return True
+    return False
+
+
 def _is_pointwise(m):
     return (isinstance(m, nn.Conv2d) and m.kernel_size == (1, 1) and m.stride == (1, 1) and m.padding == (0, 0)
             and m.dilation == (1, 1) and m.groups == 1 and m.padding_mode == "zeros")
@@ -259,8 +273,21 @@ class SS2D(nn.Module):
         out = out_proj_cf(y_cf, self.out_proj.weight, self.out_proj.bias)                    # :302, (B, d_model, L)
         return out if self.dropout is None else self.dropout(out)
 
+    def forward_modules(self, x):
+        """MedMamba.py:288-305 module by module (every sub-module through its __call__, so hooks fire); the scan itself
+        is still the HIP operator (forward_corev0 -> selective_scan_fn)."""
+        B, H, W, _ = x.shape
+        x, z = self.in_proj(x).chunk(2, dim=-1)
+        x = self.act(self.conv2d(x.permute(0, 3, 1, 2).contiguous()))
+        y1, y2, y3, y4 = self.forward_core(x)
+        y = (y1 + y2 + y3 + y4).transpose(1, 2).contiguous().view(B, H, W, -1)
+        out = self.out_proj(self.out_norm(y) * F.silu(z))
+        return out if self.dropout is None else self.dropout(out)
+
     def forward(self, x, **kwargs):
         """(B, H, W, d_model) -> (B, H, W, d_model) (MedMamba.py:288-305)."""
+        if _has_hooks(self):
+            return self.forward_modules(x)
         B, H, W, _ = x.shape
         return self.forward_cf(x).transpose(1, 2).reshape(B, H, W, -1)
 
@@ -289,7 +316,16 @@ class SS_Conv_SSM(nn.Module):
             nn.ReLU(),
         )
 
+    def forward_modules(self, input):
+        """MedMamba.py:349-357 module by module (hooks on any sub-module fire; used only when hooks are present)."""
+        left, right = input.chunk(2, dim=-1)
+        right = self.drop_path(self.self_attention(self.ln_1(right)))
+        left = self.conv33conv33conv11(left.permute(0, 3, 1, 2).contiguous()).permute(0, 2, 3, 1).contiguous()
+        return channel_shuffle(torch.cat((left, right), dim=-1), groups=2) + input
+
     def forward(self, input):
+        if _has_hooks(self) or not isinstance(self.drop_path, DropPath):
+            return self.forward_modules(input)
         if isinstance(self.ln_1, nn.LayerNorm) and self.ln_1.elementwise_affine and self.ln_1.bias is not None:
             # chunk + permute(0,3,1,2).contiguous() + ln_1 (MedMamba.py:350-352) in one fused HIP prologue
             left, right_n, input = block_split(input, self.ln_1.weight, self.ln_1.bias, self.ln_1.eps)

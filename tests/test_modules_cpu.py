@@ -150,3 +150,32 @@ def test_compat_registers_the_modules_the_reference_imports():
                 M.VSSM(num_classes=3, depths=[1, 1], dims=[16, 32]).state_dict().keys())
         finally:
             sys.path.remove(ref)
+
+
+def test_hooks_on_submodules_fire_and_do_not_change_results(oracle_scan):
+    """Grad-CAM style consumers hang hooks on `conv33conv33conv11[-2]` (test.py:101-108): a block with hooks anywhere below
+    it must run module by module (so that the hooks see the reference's tensors) and give the fused path's values."""
+    fx = load_golden("block_c16.npz")
+    blk = M.SS_Conv_SSM(hidden_dim=16, drop_path=0.0, norm_layer=torch.nn.LayerNorm)
+    blk.load_state_dict(split_sd(fx))
+    blk.train()
+    x = torch.from_numpy(fx["x"]).requires_grad_()
+    y0 = blk(x)
+    y0.backward(torch.from_numpy(fx["dy"]))
+    g0 = {k: p.grad.clone() for k, p in blk.named_parameters()}
+    blk.zero_grad(set_to_none=True)
+    seen = {}
+    h1 = blk.conv33conv33conv11[-2].register_forward_hook(lambda m, i, o: seen.__setitem__("conv", o.detach()))
+    h2 = blk.self_attention.out_norm.register_forward_hook(lambda m, i, o: seen.__setitem__("norm", o.detach()))
+    x1 = torch.from_numpy(fx["x"]).requires_grad_()
+    y1 = blk(x1)
+    y1.backward(torch.from_numpy(fx["dy"]))
+    assert set(seen) == {"conv", "norm"}
+    assert seen["conv"].shape == (x.shape[0], 8, x.shape[1], x.shape[2])           # NCHW pre-ReLU output of the 1x1 conv
+    assert seen["norm"].shape[-1] == 16                                            # (B, H, W, d_inner) as in the reference
+    assert torch.allclose(y1, y0, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(x1.grad, x.grad, rtol=1e-4, atol=1e-6)
+    for k, p in blk.named_parameters():
+        assert torch.allclose(p.grad, g0[k], rtol=1e-3, atol=1e-5), k
+    h1.remove(); h2.remove()
+    assert not M._has_hooks(blk)

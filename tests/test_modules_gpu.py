@@ -147,3 +147,24 @@ def test_block_and_tiny_model_in_both_plane_layouts(layout, monkeypatch):
     worst = max(np.abs(p.grad.cpu().numpy() - fx["grad/" + k]).max() / max(1e-3, np.abs(fx["grad/" + k]).max())
                 for k, p in net.named_parameters())
     assert worst <= 5e-3, worst
+
+
+def test_hooked_block_runs_module_by_module_on_hip():
+    """A forward hook on `conv33conv33conv11[-2]` (Grad-CAM, test.py:101-108) switches the block to the module-by-module
+    path (HIP scan operator inside); same values as the fused path and the reference fixture."""
+    from medmamba_amd import modules
+    fx = load_golden("block_c16.npz")
+    blk = modules.SS_Conv_SSM(hidden_dim=16, drop_path=0.0, norm_layer=torch.nn.LayerNorm)
+    blk.load_state_dict(split_sd(fx))
+    blk.to(DEV).train()
+    seen = []
+    h = blk.conv33conv33conv11[-2].register_forward_hook(lambda m, i, o: seen.append(o.detach()))
+    x = torch.from_numpy(fx["x"]).to(DEV).requires_grad_()
+    y = blk(x)
+    y.backward(torch.from_numpy(fx["dy"]).to(DEV))
+    assert len(seen) == 1 and seen[0].shape[1] == 8
+    _close(y, fx["y_train"], 1e-4, "y_train")
+    _close(x.grad, fx["dx"], 5e-4, "dx")
+    for k, p in blk.named_parameters():
+        _close(p.grad, fx["grad/" + k], 2e-3, k)
+    h.remove()
