@@ -125,6 +125,9 @@ def main():
 
     from medmamba_amd.modules import VSSM, MEDMAMBA_CONFIGS
     from medmamba_amd.selective_scan_interface import KERNEL_TIMER
+    from medmamba_amd.tuning import enable_tuned_gemms
+    if os.environ.get("MM_TUNED_GEMMS", "1") == "1":
+        enable_tuned_gemms()                        # recorded rocBLAS / hipBLASLt solutions per GEMM shape; no tuning at run time
     from medmamba_amd.ddp import wrap_ddp
 
     if os.environ.get("MM_MIOPEN_BENCHMARK", "0") == "1":
@@ -145,7 +148,7 @@ def main():
         loss = loss_fn(model(images), labels)
         loss.backward()
         opt.step()
-        return loss
+        return loss.detach()            # do not keep the autograd graph (and its AccumulateGrad nodes) alive across steps
 
     def fence():
         torch.cuda.synchronize()

@@ -61,3 +61,13 @@ def test_operator_has_no_cpu_fallback_and_mirrors_reference_errors():
         medmamba_amd.selective_scan_fn(u, u, A, B, B, return_last_state=True)
     with pytest.raises(NotImplementedError):
         medmamba_amd.selective_scan_fn(u, u, A, torch.zeros(1, 16, 8), B)
+
+
+def test_tuned_gemm_table_ships_and_is_inert_without_a_device():
+    from medmamba_amd.tuning import DEFAULT_FILE, enable_tuned_gemms
+    rows = [l.strip().split(",") for l in open(DEFAULT_FILE) if l.strip()]
+    assert any(r[0] == "Validator" and r[1] == "GCN_ARCH_NAME" and r[2].startswith("gfx950") for r in rows)
+    assert sum(r[0].startswith("Gemm") for r in rows) >= 40          # the MedMamba-S projection shapes
+    import torch
+    if not torch.cuda.is_available():
+        assert enable_tuned_gemms() is None

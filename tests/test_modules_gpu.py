@@ -168,3 +168,20 @@ def test_hooked_block_runs_module_by_module_on_hip():
     for k, p in blk.named_parameters():
         _close(p.grad, fx["grad/" + k], 2e-3, k)
     h.remove()
+
+
+def test_tuned_gemm_selection_keeps_the_numbers():
+    """medmamba_amd.tuning: recorded rocBLAS / hipBLASLt solutions for the projection GEMMs; same values as the default
+    heuristic's kernels (fp32 summation order aside) on a shape from the table."""
+    from medmamba_amd.tuning import enable_tuned_gemms
+    g = torch.Generator(device=DEV).manual_seed(0)
+    w = torch.randn(96, 3, device=DEV, generator=g).unsqueeze(0).expand(256, -1, -1)
+    x = torch.randn(256, 3, 3136, device=DEV, generator=g)
+    ref = torch.bmm(w, x)
+    try:
+        assert enable_tuned_gemms() is not None
+        assert torch.cuda.tunable.is_enabled() and not torch.cuda.tunable.tuning_is_enabled()
+        got = torch.bmm(w, x)
+    finally:
+        torch.cuda.tunable.enable(False)
+    assert (got - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
