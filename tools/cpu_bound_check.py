@@ -4,10 +4,12 @@ import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from medmamba_amd.modules import VSSM, MEDMAMBA_CONFIGS
+from medmamba_amd.tuning import enable_tuned_gemms
+enable_tuned_gemms()
 dev = torch.device("cuda:0")
 torch.manual_seed(42)
 net = VSSM(num_classes=6, **MEDMAMBA_CONFIGS["S"]).to(dev).train()
-opt = torch.optim.AdamW(net.parameters(), lr=1e-4, weight_decay=1e-4)
+opt = torch.optim.AdamW(net.parameters(), lr=1e-4, weight_decay=1e-4, fused=True)
 x = torch.randn(64, 3, 224, 224, device=dev); y = torch.randint(0, 6, (64,), device=dev)
 def step():
     opt.zero_grad(set_to_none=True)
