@@ -2,7 +2,7 @@
 
 hipBLASLt's default heuristics pick poor kernels for several of the skinny fp32 GEMMs of SS2D (e.g. the dt projection
 `(96 x 3) @ (3 x 3136)` batched 256 times: 0.167 ms by heuristic, 0.056 ms with the rocBLAS solution TunableOp finds).
-`gemm_gfx950.csv` holds the winners for the MedMamba-T/S shapes at 64 images per GPU, measured on an MI355X with this
+`gemm_gfx950.csv` holds the winners for the MedMamba-T/S shapes at 64 x 224^2 and the MedMamba-B shapes at 32 x 384^2 per GPU, measured on an MI355X with this
 image's ROCm 7.2 / hipBLASLt / rocBLAS builds (`tools/tune_gemms.py` regenerates it).  TunableOp validates the library
 versions and the GPU architecture recorded in the file and ignores it on any mismatch; shapes that are not in the file
 run with the default heuristic — nothing is tuned at run time unless `tune=True`.

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Regenerate medmamba_amd/tuning/gemm_gfx950.csv: run MedMamba-S training steps (64 x 224^2, the bench workload) with
 PyTorch TunableOp timing every rocBLAS / hipBLASLt solution for each GEMM shape it meets.  Run on ONE MI355X.
-usage: python tools/tune_gemms.py [out.csv] [size=S] [batch=64]"""
+usage: python tools/tune_gemms.py [out.csv] [size=S] [batch=64] [res=224] [fresh]   (without `fresh`, new shapes are added
+to an existing table — e.g. `tools/tune_gemms.py medmamba_amd/tuning/gemm_gfx950.csv B 32 384`)"""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -11,7 +12,8 @@ from medmamba_amd.tuning import DEFAULT_FILE, enable_tuned_gemms
 out = sys.argv[1] if len(sys.argv) > 1 else DEFAULT_FILE
 size = sys.argv[2] if len(sys.argv) > 2 else "S"
 batch = int(sys.argv[3]) if len(sys.argv) > 3 else 64
-if os.path.exists(out):
+res = int(sys.argv[4]) if len(sys.argv) > 4 else 224
+if "fresh" in sys.argv[5:] and os.path.exists(out):
     os.remove(out)
 torch.cuda.tunable.set_max_tuning_duration(60)      # ms per candidate
 torch.cuda.tunable.set_max_tuning_iterations(50)
@@ -20,7 +22,7 @@ dev = torch.device("cuda:0")
 torch.manual_seed(42)
 net = VSSM(num_classes=6, **MEDMAMBA_CONFIGS[size]).to(dev).train()
 opt = torch.optim.AdamW(net.parameters(), lr=1e-4, weight_decay=1e-4, fused=True)
-x = torch.randn(batch, 3, 224, 224, device=dev); y = torch.randint(0, 6, (batch,), device=dev)
+x = torch.randn(batch, 3, res, res, device=dev); y = torch.randint(0, 6, (batch,), device=dev)
 for i in range(3):
     opt.zero_grad(set_to_none=True)
     loss = torch.nn.functional.cross_entropy(net(x), y); loss.backward(); opt.step()
