@@ -57,7 +57,6 @@ constexpr int RPI = kWave / QL;  // rows per load instruction = 8
 constexpr int NLD = CH / RPI;    // row-loads per lane per tensor per tile = 2
 constexpr int NSUB = T / kChunk; // 16-step sub-tiles per tile = 2
 
-constexpr int DPP_ROW_ROR8_ = 0x128;
 
 // keep + (send of the DPP partner lane)
 template <int CTRL>
@@ -96,8 +95,9 @@ __global__ __launch_bounds__(512) void scan_bwd_kernel(const BwdParams p) {
   }
   const float Dc = p.D ? p.D[d] : 0.f;
   const float* chk_base = p.x_chk + ((int64_t)b * p.dim + d) * p.nchk * kNState + g * NS;
-  // which of the 8 reduced dB/dC sums this lane ends up with (butterfly below): idx = 4*bit2 + 2*bit0 + bit1
-  const int ridx = ((c >> 2) & 1) * 4 + (c & 1) * 2 + ((c >> 1) & 1);
+  // which of the 8 reduced dB/dC sums this lane ends up with (butterfly below): idx = 4*bit2 + 2*bit3 + bit0
+  // (the lanes with bit1 set hold duplicates and stay out of the LDS atomic)
+  const int ridx = ((c >> 2) & 1) * 4 + ((c >> 3) & 1) * 2 + (c & 1);
   float* acc_lane = sAcc + ((ridx >> 2) * kNState + g * NS + (ridx & 3)) * TS;   // + buf*2*16*TS + t
 
   // ---- staging identity: lane -> (row r of an 8-row group, float4 column q)
@@ -302,17 +302,31 @@ __global__ __launch_bounds__(512) void scan_bwd_kernel(const BwdParams p) {
           (&du4.x)[e] = fmaf(Dc, gt, pa);
           // dB/dC: 8 values x 16 lanes -> one value per lane (halving butterfly), then one LDS atomic per lane
           {
-            const bool b2 = (c >> 2) & 1, b0 = c & 1, b1 = (c >> 1) & 1;
-            float w4[4], w2[2];
-#pragma unroll
-            for (int k = 0; k < 4; ++k)               // pair i <-> i^7 (row_half_mirror); bit2 decides the kept half
-              w4[k] = dpp_add<DPP_ROW_HALF_MIRROR>(b2 ? v[4 + k] : v[k], b2 ? v[k] : v[4 + k]);
-#pragma unroll
-            for (int k = 0; k < 2; ++k)               // pair i <-> i^1; bit0 decides
-              w2[k] = dpp_add<DPP_QUAD_XOR1>(b0 ? w4[2 + k] : w4[k], b0 ? w4[k] : w4[2 + k]);
-            float w1 = dpp_add<DPP_QUAD_XOR2>(b1 ? w2[1] : w2[0], b1 ? w2[0] : w2[1]);   // pair i <-> i^2; bit1 decides
-            w1 += dpp_f<DPP_ROW_ROR8_>(w1);           // pair i <-> i^8
-            if (c < 8) atomicAdd(accb + to + e, w1);
+            // levels 1 and 2 (8 -> 4 -> 2 values) pair lanes that sit in different DPP banks (bit 2: i <-> i^7 by
+            // row_half_mirror; bit 3: i <-> i^8 by row_ror:8), so "keep one half, add the partner's copy of it" is ONE
+            // bank-masked v_add_f32_dpp per kept value and bank set — no v_cndmask.  Hand-written: the compiler cannot
+            // express a masked add whose untouched lanes keep a third register.  s_nop 1 = the 2 wait states a DPP read
+            // needs after a VALU write of the same VGPR (the hazard recogniser does not look inside inline asm); inside
+            // the block every DPP source was written >= 3 instructions earlier.
+            asm("s_nop 1\n\t"
+                "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+                "v_add_f32_dpp %0, %4, %4 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+                "v_add_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+                "v_add_f32_dpp %1, %5, %5 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+                "v_add_f32_dpp %2, %2, %2 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+                "v_add_f32_dpp %2, %6, %6 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+                "v_add_f32_dpp %3, %3, %3 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+                "v_add_f32_dpp %3, %7, %7 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+                "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+                "v_add_f32_dpp %0, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+                "v_add_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+                "v_add_f32_dpp %1, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xc"
+                : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3])
+                : "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]));
+            const bool b0 = c & 1;
+            float w1 = dpp_add<DPP_QUAD_XOR1>(b0 ? v[1] : v[0], b0 ? v[0] : v[1]);   // pair i <-> i^1; bit0 decides
+            w1 += dpp_f<DPP_QUAD_XOR2>(w1);           // pair i <-> i^2 (both lanes end with the full sum)
+            if (!(c & 2)) atomicAdd(accb + to + e, w1);
           }
         }
         if (g == 0) *reinterpret_cast<float4*>(s_dl + c * TS + to) = ddl4;
