@@ -31,7 +31,7 @@ def channel_major(B, L):
         return True
     if _LAYOUT == "bm":
         return False
-    return B > 1 and L <= 256
+    return B > 1 and L <= 256 and B * L <= 65536       # beyond that K = B*L makes the weight-gradient GEMMs split-K bound
 
 
 def _planes(B, D, L, device, cm):
