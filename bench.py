@@ -117,10 +117,9 @@ def main():
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=dev)     # "nccl" is RCCL on ROCm
-        else:
-            dist.init_process_group(backend=args.backend)
+        # "nccl" is RCCL on ROCm.  No device_id=: eager communicator binding costs 6 ms of host time per step
+        # (tools/pg_overhead.py); the communicator comes up with the first collective (GradSync's parameter broadcast)
+        dist.init_process_group(backend=args.backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from medmamba_amd.modules import VSSM, MEDMAMBA_CONFIGS
@@ -128,13 +127,16 @@ def main():
     from medmamba_amd.tuning import enable_tuned_gemms
     if os.environ.get("MM_TUNED_GEMMS", "1") == "1":
         enable_tuned_gemms()                        # recorded rocBLAS / hipBLASLt solutions per GEMM shape; no tuning at run time
-    from medmamba_amd.ddp import wrap_ddp
+    from medmamba_amd.ddp import GradSync, wrap_ddp
 
     if os.environ.get("MM_MIOPEN_BENCHMARK", "0") == "1":
         torch.backends.cudnn.benchmark = True      # MIOpen times its solvers per conv shape during the warm-up steps
     torch.manual_seed(42)                      # identical replicas; random-init weights (no checkpoints offline)
     net = VSSM(num_classes=6, **MEDMAMBA_CONFIGS[args.size]).to(dev).train()
-    model = wrap_ddp(net, dev) if world > 1 else net
+    # gradient exchange: one flat all-reduce after backward (GradSync) unless MM_DDP=torch asks for DistributedDataParallel
+    use_torch_ddp = world > 1 and os.environ.get("MM_DDP", "flat") == "torch"
+    model = wrap_ddp(net, dev) if use_torch_ddp else net
+    sync = GradSync(net) if (world > 1 and not use_torch_ddp) else None
     # train.py:189-192 (ImageFolder branch); fused=True: same update rule, one multi-tensor kernel per step
     okw = {"fused": True} if os.environ.get("MM_FUSED_ADAMW", "1") == "1" else {}      # else: torch's default (foreach)
     opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=1e-4, **okw)
@@ -147,13 +149,15 @@ def main():
         opt.zero_grad(set_to_none=True)
         loss = loss_fn(model(images), labels)
         loss.backward()
+        if sync is not None:
+            sync()
         opt.step()
         return loss.detach()            # do not keep the autograd graph (and its AccumulateGrad nodes) alive across steps
 
     def fence():
         torch.cuda.synchronize()
         if world > 1:
-            dist.barrier()
+            dist.barrier(device_ids=[local_rank]) if args.backend == "nccl" else dist.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -221,7 +225,8 @@ def main():
             "config": {"workload": f"MedMamba-{args.size} {args.res}x{args.res}x3 training step (fwd + CE loss + bwd + "
                                    f"AdamW), {args.batch} images per GPU resident in HBM, random-init weights",
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world,
-                       "parallelism": f"dp{world} (DistributedDataParallel over RCCL)" if world > 1 else "single GPU"},
+                       "parallelism": (f"dp{world} (replicas, " + ("DistributedDataParallel" if use_torch_ddp else
+                                       "one flat gradient all-reduce per step") + " over RCCL)") if world > 1 else "single GPU"},
             "roofline": roof("scan_fwd"), "roofline_bwd": roof("scan_bwd"),
             "final_loss": round(float(loss.detach()), 5),
         }

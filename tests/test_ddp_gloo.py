@@ -31,35 +31,43 @@ def _build_model():
     return net
 
 
-def _worker(rank, world, port, outdir):
+def _worker(rank, world, port, outdir, mode):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
     torch.set_num_threads(2)
-    from medmamba_amd.ddp import init_distributed, wrap_ddp
+    from medmamba_amd.ddp import GradSync, init_distributed, wrap_ddp
     assert init_distributed("gloo") == world
     net = _build_model()
     if rank == 1:                      # prove the initial broadcast: perturb rank 1's copy before wrapping
         with torch.no_grad():
             for p in net.parameters():
                 p.add_(1.0)
-    model = wrap_ddp(net)
+            for b in net.buffers():
+                if b.is_floating_point():
+                    b.add_(0.5)
+    model, sync = (wrap_ddp(net), None) if mode == "torch" else (net, GradSync(net))
     g = torch.Generator().manual_seed(100)
     x = torch.randn(4, 3, 16, 16, generator=g)[2 * rank:2 * rank + 2]
     y = torch.tensor([0, 1, 2, 1])[2 * rank:2 * rank + 2]
     loss = torch.nn.functional.cross_entropy(model(x), y)
     loss.backward()
+    if sync is not None:
+        sync()
     grads = {k: p.grad.clone() for k, p in net.named_parameters()}
     torch.save(dict(grads=grads, loss=float(loss)), os.path.join(outdir, f"r{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_ddp_gradients_match_single_process(tmp_path, monkeypatch):
+@pytest.mark.parametrize("mode", ["flat", "torch"])
+def test_ddp_gradients_match_single_process(tmp_path, monkeypatch, mode):
+    """mode "flat": medmamba_amd.ddp.GradSync (one all-reduce after backward, what bench.py uses);
+    mode "torch": DistributedDataParallel through wrap_ddp."""
     from medmamba_amd import modules as M
     for name in ("selective_scan_fn", "cross_scan_fn", "shuffle_residual", "dwconv_silu_cross", "ss2d_core", "block_split", "in_proj_cf"):
         monkeypatch.setattr(M, name, getattr(M, name))      # restore the product functions after this test
     world, port = 2, _free_port()
-    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, str(tmp_path), mode), nprocs=world, join=True)
     r0 = torch.load(tmp_path / "r0.pt")
     r1 = torch.load(tmp_path / "r1.pt")
     for k in r0["grads"]:
@@ -76,6 +84,10 @@ def test_ddp_gradients_match_single_process(tmp_path, monkeypatch):
 
 
 def test_wrap_is_identity_without_process_group():
-    from medmamba_amd.ddp import wrap_ddp
+    from medmamba_amd.ddp import GradSync, wrap_ddp
     m = torch.nn.Linear(2, 2)
     assert wrap_ddp(m) is m
+    m(torch.ones(1, 2)).sum().backward()
+    g = m.weight.grad.clone()
+    GradSync(m)()                       # world size 1: nothing to exchange
+    assert torch.equal(m.weight.grad, g)
