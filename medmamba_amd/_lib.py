@@ -11,6 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "lib", "libmedmamba_hip.so")
 
+ABI_VERSION = 7        # == MM_ABI_VERSION of include/medmamba_hip.h (checked when the library is loaded)
 _f32p = ctypes.c_void_p
 _i64 = ctypes.c_int64
 
@@ -86,7 +87,7 @@ def lib():
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(handle, name)      # AttributeError if the .so is stale
             fn.restype, fn.argtypes = res, args
-        if handle.mm_abi_version() != 7:
+        if handle.mm_abi_version() != ABI_VERSION:
             raise MedMambaHipError("libmedmamba_hip.so ABI version mismatch; rebuild")
         _lib = handle
     return _lib

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(h, name), name
         assert name in _lib.SYMBOLS, f"{name} declared in the header but not bound in _lib.SYMBOLS"
     assert set(_lib.SYMBOLS) <= set(decl)
-    assert _lib.lib().mm_abi_version() == 7
+    assert _lib.lib().mm_abi_version() == _lib.ABI_VERSION == int(re.search(r"#define MM_ABI_VERSION (\d+)", open(os.path.join(ROOT, "include", "medmamba_hip.h")).read()).group(1))
     assert _lib.scan_chunk() == 16
     assert b"unsupported" in _lib.lib().mm_status_string(-3)
 
@@ -71,3 +71,9 @@ def test_tuned_gemm_table_ships_and_is_inert_without_a_device():
     import torch
     if not torch.cuda.is_available():
         assert enable_tuned_gemms() is None
+
+
+def test_graft_entry_build_runs():
+    """The driver's build check: compiles the HIP library and the C oracle and imports the package."""
+    import __graft_entry__
+    __graft_entry__.build()
