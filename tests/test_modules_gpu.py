@@ -185,3 +185,31 @@ def test_tuned_gemm_selection_keeps_the_numbers():
     finally:
         torch.cuda.tunable.enable(False)
     assert (got - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
+
+
+def test_odd_and_non_square_images_same_in_both_layouts(monkeypatch, capsys):
+    """72 x 40 input: stage grids 18x10, 9x5, 4x2 (PatchMerging crops the odd 9x5, MedMamba.py:97-111), 2x1 — non-square,
+    odd, unaligned (L % 4 != 0) planes through every kernel; batch-major and channel-major storage must agree, and the
+    single-stream schedule with them."""
+    from medmamba_amd import modules, ops
+    torch.manual_seed(11)
+    net = modules.VSSM(num_classes=4, depths=[1, 1, 1, 1], dims=[16, 32, 64, 128], drop_path_rate=0.0).to(DEV).train()
+    x = torch.randn(3, 3, 72, 40, device=DEV)
+    y = torch.randint(0, 4, (3,), device=DEV)
+
+    def run(layout, two):
+        monkeypatch.setattr(ops, "_LAYOUT", layout)
+        monkeypatch.setattr(modules, "_TWO_STREAMS", two)
+        net.zero_grad(set_to_none=True)
+        logits = net(x)
+        torch.nn.functional.cross_entropy(logits, y).backward()
+        return logits.detach().clone(), {k: p.grad.clone() for k, p in net.named_parameters()}
+
+    l0, g0 = run("bm", False)
+    for layout, two in (("cm", False), ("auto", True), ("cm", True)):
+        l1, g1 = run(layout, two)
+        assert (l1 - l0).abs().max().item() <= 1e-4 * max(1.0, l0.abs().max().item()), layout
+        for k in g0:
+            scale = max(1e-4, g0[k].abs().max().item())
+            assert (g1[k] - g0[k]).abs().max().item() <= 2e-3 * scale, (layout, two, k)
+    capsys.readouterr()         # the crop warning of PatchMerging2D
