@@ -729,31 +729,48 @@ __host__ __device__ __forceinline__ PackSeg pack_layout(int D, int C, int R, int
 }
 
 // BWD = false: P[packed] = f(src_seg[k-order]);  BWD = true: G[k-order, same segment layout] = dP[packed] * (A-seg ? P : 1)
+// One workgroup = 256 consecutive elements of one (segment, direction): the index math is wave-uniform (no per-thread
+// division), reads and writes are contiguous runs.  blk_off[s] = first workgroup of segment s, nb[s] = workgroups per
+// direction of segment s (computed on the host).
+struct PackGrid { int blk_off[6]; int nb[5]; };
+
 template <bool BWD>
 __global__ __launch_bounds__(256) void ss2d_pack_kernel(const float* __restrict__ s0, const float* __restrict__ s1,
                                                         const float* __restrict__ s2, const float* __restrict__ s3,
                                                         const float* __restrict__ s4, float* __restrict__ dst, int D, int C,
-                                                        int R, int N) {
+                                                        int R, int N, PackGrid pg) {
   const PackSeg L = pack_layout(D, C, R, N);
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= L.off[5]) return;
+  const int b = blockIdx.x;
   int seg = 0;
 #pragma unroll
-  for (int q = 1; q < 5; ++q) seg += i >= L.off[q];
-  const int local = i - L.off[seg], pd = L.per_dir[seg];
-  if (local >= 4 * pd) return;          // alignment padding between segments
-  const int g = local / pd, rem = local - g * pd;
-  const int k = ((g & 1) << 1) | (g >> 1);
-  const int j = k * pd + rem;           // index inside the segment, reference direction order
+  for (int q = 1; q < 5; ++q) seg += b >= pg.blk_off[q];
+  const int lb = b - pg.blk_off[seg], nbs = pg.nb[seg];
+  const int g = lb / nbs, chunk = lb - g * nbs;            // wave-uniform
+  const int pd = L.per_dir[seg];
+  const int rem = chunk * 256 + threadIdx.x;
+  if (rem >= pd) return;
+  const int k = ((g & 1) << 1) | (g >> 1);                 // reference direction of kernel direction g (an involution)
+  const int i = L.off[seg] + g * pd + rem;                 // packed index (kernel order)
+  const int j = k * pd + rem;                              // index inside the segment, reference direction order
   if constexpr (!BWD) {
     const float* src = seg == 0 ? s0 : seg == 1 ? s1 : seg == 2 ? s3 : seg == 3 ? s4 : s2;   // (Wx, Wdt, bias, A_logs, Ds)
     const float v = src[j];
     dst[i] = seg == 2 ? -expf(v) : v;
   } else {
     // s0 = dP (packed), s1 = P (packed): d(A_logs) = dA * A
-    const float v = s0[i] * (seg == 2 ? s1[i] : 1.0f);
-    dst[L.off[seg] + j] = v;
+    dst[L.off[seg] + j] = s0[i] * (seg == 2 ? s1[i] : 1.0f);
   }
+}
+
+inline PackGrid pack_grid(int D, int C, int R, int N) {
+  const PackSeg L = pack_layout(D, C, R, N);
+  PackGrid pg;
+  pg.blk_off[0] = 0;
+  for (int s = 0; s < 5; ++s) {
+    pg.nb[s] = (L.per_dir[s] + 255) / 256;
+    pg.blk_off[s + 1] = pg.blk_off[s] + 4 * pg.nb[s];
+  }
+  return pg;
 }
 }  // namespace
 
@@ -765,18 +782,18 @@ int mm_ss2d_pack_fwd(const float* x_proj_w, const float* dt_w, const float* dt_b
                      float* packed, int D, int C, int R, int N, void* stream) {
   if (!x_proj_w || !dt_w || !dt_b || !A_logs || !Ds || !packed) return MM_ERR_NULL;
   if (D <= 0 || C <= 0 || R <= 0 || N <= 0) return MM_ERR_SHAPE;
-  const int n = mm_ss2d_pack_size(D, C, R, N);
-  hipLaunchKernelGGL(ss2d_pack_kernel<false>, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, x_proj_w, dt_w, dt_b,
-                     A_logs, Ds, packed, D, C, R, N);
+  const PackGrid pg = pack_grid(D, C, R, N);
+  hipLaunchKernelGGL(ss2d_pack_kernel<false>, dim3(pg.blk_off[5]), dim3(256), 0, (hipStream_t)stream, x_proj_w, dt_w, dt_b,
+                     A_logs, Ds, packed, D, C, R, N, pg);
   return (int)hipGetLastError();
 }
 
 int mm_ss2d_pack_bwd(const float* dpacked, const float* packed, float* grads, int D, int C, int R, int N, void* stream) {
   if (!dpacked || !packed || !grads) return MM_ERR_NULL;
   if (D <= 0 || C <= 0 || R <= 0 || N <= 0) return MM_ERR_SHAPE;
-  const int n = mm_ss2d_pack_size(D, C, R, N);
-  hipLaunchKernelGGL(ss2d_pack_kernel<true>, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, dpacked, packed, nullptr,
-                     nullptr, nullptr, grads, D, C, R, N);
+  const PackGrid pg = pack_grid(D, C, R, N);
+  hipLaunchKernelGGL(ss2d_pack_kernel<true>, dim3(pg.blk_off[5]), dim3(256), 0, (hipStream_t)stream, dpacked, packed, nullptr,
+                     nullptr, nullptr, grads, D, C, R, N, pg);
   return (int)hipGetLastError();
 }
 
