@@ -266,7 +266,7 @@ class SS2DCoreFn(torch.autograd.Function):
                 P[o3:o3 + 4 * D], P[o4:o4 + 4 * D])
 
     @staticmethod
-    def forward(ctx, u2, x_proj_w, dt_w, dt_b, A_logs, Ds, z_cf, ln_w, ln_b, H, W, eps):
+    def forward(ctx, u2, x_proj_w, dt_w, dt_b, A_logs, Ds, z_cf, ln_w, ln_b, H, W, eps, prescan_event=None):
         from .selective_scan_interface import _CROSS_SHARED, _launch_fwd
         Bsz, D2, L = u2.shape
         D, R, N = D2 // 2, dt_w.shape[2], A_logs.shape[1]
@@ -292,6 +292,8 @@ class SS2DCoreFn(torch.autograd.Function):
             delta = torch.matmul(Wdt.unsqueeze(0), x_dbl[:, :, :R]).view(Bsz, 4 * D, L)
             xb = x_dbl
         need_grad = any(ctx.needs_input_grad)
+        if prescan_event is not None:
+            prescan_event.record()          # the projections are queued; what follows is the (latency-bound) scan
         out4, x_chk = _launch_fwd(u2, delta, A, xb[:, :, R:R + N], xb[:, :, R + N:], Dp, dbias, True, need_grad, 0,
                                   _CROSS_SHARED)
         z_cf = _rows(z_cf)
@@ -375,18 +377,22 @@ class SS2DCoreFn(torch.autograd.Function):
             rc = lib.mm_ss2d_pack_bwd(dP.data_ptr(), P.data_ptr(), G.data_ptr(), D, C, R, N, _stream())
         _lib.check(rc, "mm_ss2d_pack_bwd")
         gWx, gWdt, gA, gD, gb = SS2DCoreFn._segments(G, D, C, R, N)
-        return (du2, gWx, gWdt, gb.view(4, D), gA, gD, dz, wsum[:D], wsum[D:], None, None, None)
+        return (du2, gWx, gWdt, gb.view(4, D), gA, gD, dz, wsum[:D], wsum[D:], None, None, None, None)
 
 
-def ss2d_core(u2, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds, z_cf, ln_w, ln_b, H, W, eps=1e-5):
-    """Parameters in the module's own (reference) layout and direction order; see SS2DCoreFn."""
+def ss2d_core(u2, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds, z_cf, ln_w, ln_b, H, W, eps=1e-5,
+              prescan_event=None):
+    """Parameters in the module's own (reference) layout and direction order; see SS2DCoreFn.
+    prescan_event: optional torch.cuda.Event recorded on the current stream right before the scan kernel is queued (lets a
+    caller start independent work on another stream exactly when the latency-bound scan begins)."""
     _need_hip(u2, z_cf)
     D = u2.shape[1] // 2
     if (A_logs.shape != (4 * D, 16) or x_proj_weight.shape[0] != 4 or x_proj_weight.shape[2] != D
             or dt_projs_weight.shape[:2] != (4, D) or dt_projs_bias.shape != (4, D) or Ds.shape != (4 * D,)
             or x_proj_weight.shape[1] != dt_projs_weight.shape[2] + 32):
         raise NotImplementedError("ss2d_core: expects 4 directions, d_state 16, u2 with 2*D channels")
-    return SS2DCoreFn.apply(u2, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds, z_cf, ln_w, ln_b, H, W, eps)
+    return SS2DCoreFn.apply(u2, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds, z_cf, ln_w, ln_b, H, W, eps,
+                            prescan_event)
 
 
 class BlockSplitFn(torch.autograd.Function):

@@ -180,7 +180,8 @@ def dwconv_silu_cross_ref(x_cf, weight, bias, H, W):
     return torch.stack([xc.reshape(B, D, L), xc.transpose(2, 3).reshape(B, D, L)], 1).reshape(B, 2 * D, L)
 
 
-def ss2d_core_ref(u2, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds, z_cf, ln_w, ln_b, H, W, eps=1e-5):
+def ss2d_core_ref(u2, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds, z_cf, ln_w, ln_b, H, W, eps=1e-5,
+                  prescan_event=None):
     """Test double for medmamba_amd.ops.ss2d_core: the x / dt projections (MedMamba.py:259-262) as einsums, A = -exp(A_logs)
     (:271), the oracle scan on explicitly flipped tensors, the reference's merge (:282-286, 298), out_norm (:300) and gate
     (:301), channel-first.  Parameters in the module's (reference) direction order k; the scan double wants kernel order g."""
