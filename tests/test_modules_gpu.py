@@ -103,6 +103,7 @@ def test_two_stream_blocks_match_single_stream(monkeypatch):
 
     def run(two, it):
         monkeypatch.setattr(modules, "_TWO_STREAMS", two)
+        monkeypatch.setattr(modules, "_LATE_SIDE_MIN_L", 0 if it % 2 else 1 << 30)   # late / early start of the side stream
         net.zero_grad(set_to_none=True)
         junk = [torch.empty(1 << (16 + (it + j) % 6), device=DEV).normal_() for j in range(4)]   # churn the allocator
         loss = torch.nn.functional.cross_entropy(net(x), y)
