@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MM_ABI_VERSION 7
+#define MM_ABI_VERSION 8
 
 enum mm_status {
   MM_OK = 0,
@@ -141,11 +141,14 @@ int mm_shuffle_residual_bwd(const float* dout, float* dleft, float* dssm, int64_
  *   x planes (b,d) of H*W floats at x + b*x_sb + d*x_sd; w (D,1,3,3); bias (D) or NULL;
  *   u2 = 2*D planes per batch item (plane (b, j*D+d) at u2 + b*u2_sb + (j*D+d)*u2_sd):
  *   u2[b,0,d,h*W+w] = u2[b,1,d,w*H+h] = silu(conv(x)[b,d,h,w] + bias[d]).
- * mm_dwconv_silu_cross_bwd: du2 (same plane indexing) -> dx planes and per-plane partial sums
+ * mm_dwconv_silu_cross_bwd: du2 (same plane indexing) [+ du4 or NULL: the scan's per-direction input gradients, 4*D
+ *   planes per batch item, plane (b, k*D+d) at du4 + b*du4_sb + (k*D+d)*du4_sd; directions 0,1 add to the row-major image,
+ *   2,3 to the column-major one] -> dx planes and per-plane partial sums
  *   ws[(b*D+d)*10 + (0..8: dW[kh][kw], 9: dbias)]  (the caller sums over b). */
 int mm_dwconv_silu_cross_fwd(const float* x, int64_t x_sb, int64_t x_sd, const float* w, const float* bias, float* u2,
                              int64_t u2_sb, int64_t u2_sd, int batch, int D, int H, int W, void* stream);
-int mm_dwconv_silu_cross_bwd(const float* du2, int64_t du2_sb, int64_t du2_sd, const float* x, int64_t x_sb, int64_t x_sd,
+int mm_dwconv_silu_cross_bwd(const float* du2, int64_t du2_sb, int64_t du2_sd, const float* du4, int64_t du4_sb, int64_t du4_sd,
+                             const float* x, int64_t x_sb, int64_t x_sd,
                              const float* w, const float* bias, float* dx, int64_t dx_sb, int64_t dx_sd, float* ws, int batch,
                              int D, int H, int W, void* stream);
 /* cross-merge (MedMamba.py:282-286 + the 4-way sum of :298), all tensors in position order:

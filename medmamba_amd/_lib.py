@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "lib", "libmedmamba_hip.so")
 
-ABI_VERSION = 7        # == MM_ABI_VERSION of include/medmamba_hip.h (checked when the library is loaded)
+ABI_VERSION = 8        # == MM_ABI_VERSION of include/medmamba_hip.h (checked when the library is loaded)
 _f32p = ctypes.c_void_p
 _i64 = ctypes.c_int64
 
@@ -46,7 +46,7 @@ SYMBOLS = {
     "mm_scan_bwd": (ctypes.c_int, [ctypes.POINTER(ScanArgs), ctypes.c_void_p]),
     "mm_shuffle_residual_fwd": (ctypes.c_int, [_f32p, _f32p, _i64, _i64, _f32p, _f32p, _f32p] + [ctypes.c_int] * 5 + [ctypes.c_void_p]),
     "mm_dwconv_silu_cross_fwd": (ctypes.c_int, [_f32p, _i64, _i64, _f32p, _f32p, _f32p, _i64, _i64] + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
-    "mm_dwconv_silu_cross_bwd": (ctypes.c_int, [_f32p, _i64, _i64, _f32p, _i64, _i64, _f32p, _f32p, _f32p, _i64, _i64, _f32p]
+    "mm_dwconv_silu_cross_bwd": (ctypes.c_int, [_f32p, _i64, _i64, _f32p, _i64, _i64, _f32p, _i64, _i64, _f32p, _f32p, _f32p, _i64, _i64, _f32p]
                                  + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
     "mm_cross_merge_fwd": (ctypes.c_int, [_f32p, _f32p, _i64, _i64] + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
     "mm_plane_transpose": (ctypes.c_int, [_f32p, _i64, _i64, _f32p, _i64, _i64] + [ctypes.c_int] * 4 + [ctypes.c_void_p]),

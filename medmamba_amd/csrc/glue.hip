@@ -168,7 +168,11 @@ __global__ __launch_bounds__(256) void dwconv_silu_cross_fwd_kernel(const float*
 
 // backward of the above: g = du2[b,0] + T(du2[b,1]);  dp = g * silu'(p);  dx = corr(dp, flipped k);
 // per-plane partial weight/bias gradients to ws[(b*D+d)*10 + 0..8 | 9].
+// du4 (optional): the scan's per-direction gradients of its input, 4*D planes per batch item; directions (0,1) read the
+// row-major image and (2,3) the column-major one, so du2[b,j] += du4[b,2j] + du4[b,2j+1] is folded into the loads here
+// (saves the pair-sum kernel and the read-modify-write of the projection GEMM that would otherwise accumulate into it).
 __global__ __launch_bounds__(256) void dwconv_silu_cross_bwd_kernel(const float* __restrict__ du2, int64_t g_sb, int64_t g_sd,
+                                                                    const float* __restrict__ du4, int64_t e_sb, int64_t e_sd,
                                                                     const float* __restrict__ x, int64_t x_sb, int64_t x_sd,
                                                                     const float* __restrict__ wgt,
                                                                     const float* __restrict__ bias, float* __restrict__ dx,
@@ -184,6 +188,8 @@ __global__ __launch_bounds__(256) void dwconv_silu_cross_bwd_kernel(const float*
   const float* xp = x + (int64_t)b * x_sb + (int64_t)d * x_sd;
   const float* g0 = du2 + b * g_sb + d * g_sd;
   const float* g1 = du2 + b * g_sb + (D + d) * g_sd;
+  const float* e0 = du4 ? du4 + b * e_sb + d * e_sd : nullptr;          // direction 0; direction k at e0 + k*D*e_sd
+  const int64_t eD = (int64_t)D * e_sd;
   for (int i = tid; i < (H + 2) * WP; i += nt) {
     const int hh = i / WP - 1, ww = i % WP - 1;
     sx[i] = (hh >= 0 && hh < H && ww >= 0 && ww < W) ? xp[hh * W + ww] : 0.f;
@@ -191,7 +197,7 @@ __global__ __launch_bounds__(256) void dwconv_silu_cross_bwd_kernel(const float*
   }
   for (int i = tid; i < L; i += nt) {       // i = w*H + h
     const int w = i / H, h = i % H;
-    st[h * (W + 1) + w] = g1[i];
+    st[h * (W + 1) + w] = g1[i] + (e0 ? e0[2 * eD + i] + e0[3 * eD + i] : 0.f);
   }
   float k[9];
 #pragma unroll
@@ -210,7 +216,8 @@ __global__ __launch_bounds__(256) void dwconv_silu_cross_bwd_kernel(const float*
 #pragma unroll
       for (int kw = 0; kw < 3; ++kw) p = fmaf(c[kh * WP + kw], k[kh * 3 + kw], p);
     const float s = sigmoid_f(p);
-    const float dp = (g0[i] + st[h * (W + 1) + w]) * (s * (1.f + p * (1.f - s)));   // silu'(p) = s (1 + p (1 - s))
+    const float ge = e0 ? e0[i] + e0[eD + i] : 0.f;
+    const float dp = (g0[i] + ge + st[h * (W + 1) + w]) * (s * (1.f + p * (1.f - s)));   // silu'(p) = s (1 + p (1 - s))
     sd[(h + 1) * WP + (w + 1)] = dp;
     acc[9] += dp;
 #pragma unroll
@@ -437,7 +444,8 @@ int mm_dwconv_silu_cross_fwd(const float* x, int64_t x_sb, int64_t x_sd, const f
   return (int)hipGetLastError();
 }
 
-int mm_dwconv_silu_cross_bwd(const float* du2, int64_t du2_sb, int64_t du2_sd, const float* x, int64_t x_sb, int64_t x_sd,
+int mm_dwconv_silu_cross_bwd(const float* du2, int64_t du2_sb, int64_t du2_sd, const float* du4, int64_t du4_sb, int64_t du4_sd,
+                             const float* x, int64_t x_sb, int64_t x_sd,
                              const float* w, const float* bias, float* dx, int64_t dx_sb, int64_t dx_sd, float* ws, int batch,
                              int D, int H, int W, void* stream) {
   if (!du2 || !x || !w || !dx || !ws) return MM_ERR_NULL;
@@ -446,7 +454,8 @@ int mm_dwconv_silu_cross_bwd(const float* du2, int64_t du2_sb, int64_t du2_sd, c
   if (lds > 150 * 1024) return MM_ERR_UNSUPPORTED;
   const int L = H * W, nt = L >= 1024 ? 256 : (L > 64 ? 128 : 64);
   if (lds > 60 * 1024) (void)hipFuncSetAttribute((const void*)dwconv_silu_cross_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(dwconv_silu_cross_bwd_kernel, dim3(batch * D), dim3(nt), lds, (hipStream_t)stream, du2, du2_sb, du2_sd, x, x_sb,
+  hipLaunchKernelGGL(dwconv_silu_cross_bwd_kernel, dim3(batch * D), dim3(nt), lds, (hipStream_t)stream, du2, du2_sb, du2_sd, du4, du4_sb,
+                     du4_sd, x, x_sb,
                      x_sd, w, bias, dx, dx_sb, dx_sd, ws, D, H, W);
   return (int)hipGetLastError();
 }

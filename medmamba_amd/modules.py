@@ -24,7 +24,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 import torch.utils.checkpoint as checkpoint
 
-from .ops import block_split, dwconv_silu_cross, in_proj_cf, out_proj_cf, shuffle_residual, ss2d_core
+from .ops import block_split, dwconv_silu_cross, in_proj_cf, out_proj_cf, shuffle_residual, ss2d_conv_core, ss2d_core
 from .selective_scan_interface import CROSS_SCAN_K_OF_G, cross_scan_fn, selective_scan_fn
 
 trunc_normal_ = nn.init.trunc_normal_   # timm.layers.trunc_normal_ == torch.nn.init.trunc_normal_
@@ -267,12 +267,21 @@ class SS2D(nn.Module):
         B, H, W, _ = x.shape
         L, D, R, N = H * W, self.d_inner, self.dt_rank, self.d_state
         x_cf, z_cf = in_proj_cf(x.reshape(B, L, -1), self.in_proj.weight, self.in_proj.bias)  # :291-292, (B, D, L) each
-        u2 = dwconv_silu_cross(x_cf, self.conv2d.weight, self.conv2d.bias, H, W)            # :294-295 + :256
-        # projections (:259-262), A = -exp(A_logs) (:271), scan, merge, out_norm and gate (:273-301); the parameters go in
-        # as the module holds them, the kernel-order packing is one launch inside
-        y_cf = ss2d_core(u2, self.x_proj_weight, self.dt_projs_weight, self.dt_projs_bias, self.A_logs, self.Ds,
-                         z_cf, self.out_norm.weight, self.out_norm.bias, H, W, self.out_norm.eps,
-                         prescan_event=prescan_event)
+        # depthwise conv + SiLU (:294-295) writing both image orders of :256, projections (:259-262), A = -exp(A_logs)
+        # (:271), scan, merge, out_norm and gate (:273-301) — one autograd Function; the parameters go in as the module
+        # holds them, the kernel-order packing is one launch inside
+        cv = self.conv2d
+        if cv.kernel_size == (3, 3) and cv.padding == (1, 1) and cv.stride == (1, 1) and cv.dilation == (1, 1) \
+                and cv.groups == D and cv.padding_mode == "zeros":
+            y_cf = ss2d_conv_core(x_cf, cv.weight, cv.bias, self.x_proj_weight, self.dt_projs_weight, self.dt_projs_bias,
+                                  self.A_logs, self.Ds, z_cf, self.out_norm.weight, self.out_norm.bias, H, W,
+                                  self.out_norm.eps, prescan_event=prescan_event)
+        else:                   # any other d_conv: the conv through MIOpen, then the core on its two image orders
+            xc = self.act(cv(x_cf.reshape(B, D, H, W)))
+            u2 = torch.stack([xc.reshape(B, D, L), xc.transpose(2, 3).reshape(B, D, L)], 1).reshape(B, 2 * D, L)
+            y_cf = ss2d_core(u2, self.x_proj_weight, self.dt_projs_weight, self.dt_projs_bias, self.A_logs, self.Ds,
+                             z_cf, self.out_norm.weight, self.out_norm.bias, H, W, self.out_norm.eps,
+                             prescan_event=prescan_event)
         out = out_proj_cf(y_cf, self.out_proj.weight, self.out_proj.bias)                    # :302, (B, d_model, L)
         return out if self.dropout is None else self.dropout(out)
 

@@ -222,7 +222,7 @@ class DwConvSiluCrossFn(torch.autograd.Function):
         dx = _planes(B, D, L, du2.device, ctx.cm)
         ws = torch.empty((B, D, 10), device=du2.device, dtype=torch.float32)
         with _lib.device_guard(du2.device):
-            rc = _lib.lib().mm_dwconv_silu_cross_bwd(*_pl(du2), *_pl(x_cf), weight.data_ptr(),
+            rc = _lib.lib().mm_dwconv_silu_cross_bwd(*_pl(du2), None, 0, 0, *_pl(x_cf), weight.data_ptr(),
                                                      None if bias is None else bias.data_ptr(), *_pl(dx), ws.data_ptr(),
                                                      B, D, H, W, _stream())
         _lib.check(rc, "mm_dwconv_silu_cross_bwd")
@@ -266,14 +266,29 @@ class SS2DCoreFn(torch.autograd.Function):
                 P[o3:o3 + 4 * D], P[o4:o4 + 4 * D])
 
     @staticmethod
-    def forward(ctx, u2, x_proj_w, dt_w, dt_b, A_logs, Ds, z_cf, ln_w, ln_b, H, W, eps, prescan_event=None):
+    def forward(ctx, u2, conv_w, conv_b, x_proj_w, dt_w, dt_b, A_logs, Ds, z_cf, ln_w, ln_b, H, W, eps, prescan_event=None):
         from .selective_scan_interface import _CROSS_SHARED, _launch_fwd
-        Bsz, D2, L = u2.shape
+        lib = _lib.lib()
+        dev = u2.device
+        L = u2.shape[2]
+        Bsz = u2.shape[0]
+        cm = channel_major(Bsz, L)
+        x_cf = None
+        if conv_w is not None:
+            # depthwise conv3x3 + SiLU (MedMamba.py:294-295) inside the Function: u2 is (B, D, L) = x here, and the backward
+            # hands the three contributions to d(u2) — two direction pairs of the scan + the x projection — to ONE kernel
+            x_cf = _rows(u2)
+            conv_w = conv_w.float().contiguous()
+            conv_b = None if conv_b is None else conv_b.float().contiguous()
+            Dc = x_cf.shape[1]
+            u2 = _planes(Bsz, 2 * Dc, L, dev, cm)
+            with _lib.device_guard(dev):
+                rc = lib.mm_dwconv_silu_cross_fwd(*_pl(x_cf), conv_w.data_ptr(), None if conv_b is None else conv_b.data_ptr(),
+                                                  *_pl(u2), Bsz, Dc, H, W, _stream())
+            _lib.check(rc, "mm_dwconv_silu_cross_fwd")
+        D2 = u2.shape[1]
         D, R, N = D2 // 2, dt_w.shape[2], A_logs.shape[1]
         C, Q = R + 2 * N, Bsz * L
-        dev = u2.device
-        lib = _lib.lib()
-        cm = channel_major(Bsz, L)
         srcs = [t.float().contiguous() for t in (x_proj_w, dt_w, dt_b, A_logs, Ds)]
         P = torch.empty((lib.mm_ss2d_pack_size(D, C, R, N),), device=dev, dtype=torch.float32)
         with _lib.device_guard(dev):
@@ -309,14 +324,15 @@ class SS2DCoreFn(torch.autograd.Function):
                                     mu.data_ptr(), rstd.data_ptr(), Bsz, D, L, _stream())
             _lib.check(rc, "mm_ln_gate_fwd")
         if need_grad:
-            ctx.save_for_backward(u2, x_dbl, delta, P, x_chk, m, mu, rstd, z_cf, ln_w, ln_b)
+            ctx.save_for_backward(u2, x_dbl, delta, P, x_chk, m, mu, rstd, z_cf, ln_w, ln_b, x_cf, conv_w, conv_b)
             ctx.dims = (H, W, D, C, R, N, cm)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         from .selective_scan_interface import _CROSS_SHARED, _launch_bwd
-        u2, x_dbl, delta, P, x_chk, m, mu, rstd, z_cf, ln_w, ln_b = ctx.saved_tensors
+        u2, x_dbl, delta, P, x_chk, m, mu, rstd, z_cf, ln_w, ln_b, x_cf, conv_w, conv_b = ctx.saved_tensors
+        fused_conv = conv_w is not None
         H, W, D, C, R, N, cm = ctx.dims
         Wx, Wdt, A, Dp, dbias = SS2DCoreFn._segments(P, D, C, R, N)
         Bsz, _, L = m.shape
@@ -353,10 +369,13 @@ class SS2DCoreFn(torch.autograd.Function):
             dd = ddelta.permute(1, 0, 2).reshape(4, D, Q)                                      # views of (4D, B, L) storage
             torch.bmm(dd, x_dbl[:, :R].transpose(1, 2), out=dWdt)                               # (4, D, R)
             dx_dbl[:, :R] = torch.bmm(Wdt.transpose(1, 2), dd)                                  # dt rows of d(x_dbl)
-            d4 = du4.permute(1, 0, 2).reshape(2, 2, D, Q)
-            du2m = d4[:, 0] + d4[:, 1]                                                         # the two directions of a pair
             dx2 = dx_dbl.view(2, 2 * C, Q)
-            du2m.baddbmm_(Wx.view(2, 2 * C, D).transpose(1, 2), dx2)                             # + Wx^T d(x_dbl)
+            if fused_conv:
+                du2m = torch.bmm(Wx.view(2, 2 * C, D).transpose(1, 2), dx2)                      # Wx^T d(x_dbl); pairs added later
+            else:
+                d4 = du4.permute(1, 0, 2).reshape(2, 2, D, Q)
+                du2m = d4[:, 0] + d4[:, 1]                                                     # the two directions of a pair
+                du2m.baddbmm_(Wx.view(2, 2 * C, D).transpose(1, 2), dx2)                         # + Wx^T d(x_dbl)
             torch.bmm(dx2, _cm2d(u2).view(2, D, Q).transpose(1, 2), out=dWx.view(2, 2 * C, D))
             du2 = du2m.view(2 * D, Bsz, L).permute(1, 0, 2)
         else:
@@ -364,12 +383,15 @@ class SS2DCoreFn(torch.autograd.Function):
             xr = x_dbl[:, :, :R]
             torch.sum(torch.matmul(dd, xr.transpose(-1, -2)), 0, out=dWdt)                       # (4, D, R)
             dx_dbl[:, :, :R] = torch.matmul(Wdt.transpose(-1, -2).unsqueeze(0), dd)               # dt rows of d(x_dbl)
-            d4 = du4.view(Bsz, 2, 2, D, L)
-            du2 = (d4[:, :, 0] + d4[:, :, 1]).view(Bsz * 2, D, L)                                 # the two directions of a pair
             Wx2 = Wx.view(2, 2 * C, D)
             dxd2 = dx_dbl.view(Bsz, 2, 2 * C, L)
-            du2.baddbmm_(Wx2.transpose(1, 2).unsqueeze(0).expand(Bsz, -1, -1, -1).reshape(Bsz * 2, D, 2 * C),
-                         dxd2.reshape(Bsz * 2, 2 * C, L))                                       # + Wx^T d(x_dbl)
+            WxT = Wx2.transpose(1, 2).unsqueeze(0).expand(Bsz, -1, -1, -1).reshape(Bsz * 2, D, 2 * C)
+            if fused_conv:
+                du2 = torch.bmm(WxT, dxd2.reshape(Bsz * 2, 2 * C, L))                            # Wx^T d(x_dbl); pairs added later
+            else:
+                d4 = du4.view(Bsz, 2, 2, D, L)
+                du2 = (d4[:, :, 0] + d4[:, :, 1]).view(Bsz * 2, D, L)                             # the two directions of a pair
+                du2.baddbmm_(WxT, dxd2.reshape(Bsz * 2, 2 * C, L))                               # + Wx^T d(x_dbl)
             torch.sum(torch.matmul(dxd2, u2.view(Bsz, 2, D, L).transpose(-1, -2)), 0, out=dWx.view(2, 2 * C, D))
             du2 = du2.view(Bsz, 2 * D, L)
         G = torch.empty_like(P)
@@ -377,7 +399,19 @@ class SS2DCoreFn(torch.autograd.Function):
             rc = lib.mm_ss2d_pack_bwd(dP.data_ptr(), P.data_ptr(), G.data_ptr(), D, C, R, N, _stream())
         _lib.check(rc, "mm_ss2d_pack_bwd")
         gWx, gWdt, gA, gD, gb = SS2DCoreFn._segments(G, D, C, R, N)
-        return (du2, gWx, gWdt, gb.view(4, D), gA, gD, dz, wsum[:D], wsum[D:], None, None, None, None)
+        dcw = dcb = None
+        if fused_conv:
+            # d(u2) = projection part (du2) + the scan's two direction pairs (du4), summed inside the conv's backward kernel
+            dxc = _planes(Bsz, D, L, dev, cm)
+            wsc = torch.empty((Bsz, D, 10), device=dev, dtype=torch.float32)
+            with _lib.device_guard(dev):
+                rc = lib.mm_dwconv_silu_cross_bwd(*_pl(du2), *_pl(du4), *_pl(x_cf), conv_w.data_ptr(),
+                                                  None if conv_b is None else conv_b.data_ptr(), *_pl(dxc), wsc.data_ptr(),
+                                                  Bsz, D, H, W, _stream())
+            _lib.check(rc, "mm_dwconv_silu_cross_bwd")
+            sc = wsc.sum(0)
+            du2, dcw, dcb = dxc, sc[:, :9].reshape(D, 1, 3, 3), (None if conv_b is None else sc[:, 9])
+        return (du2, dcw, dcb, gWx, gWdt, gb.view(4, D), gA, gD, dz, wsum[:D], wsum[D:], None, None, None, None)
 
 
 def ss2d_core(u2, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds, z_cf, ln_w, ln_b, H, W, eps=1e-5,
@@ -391,8 +425,23 @@ def ss2d_core(u2, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds, z_c
             or dt_projs_weight.shape[:2] != (4, D) or dt_projs_bias.shape != (4, D) or Ds.shape != (4 * D,)
             or x_proj_weight.shape[1] != dt_projs_weight.shape[2] + 32):
         raise NotImplementedError("ss2d_core: expects 4 directions, d_state 16, u2 with 2*D channels")
-    return SS2DCoreFn.apply(u2, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds, z_cf, ln_w, ln_b, H, W, eps,
-                            prescan_event)
+    return SS2DCoreFn.apply(u2, None, None, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds, z_cf, ln_w, ln_b, H, W,
+                            eps, prescan_event)
+
+
+def ss2d_conv_core(x_cf, conv_weight, conv_bias, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds, z_cf, ln_w, ln_b,
+                   H, W, eps=1e-5, prescan_event=None):
+    """dwconv_silu_cross + ss2d_core in ONE autograd Function (MedMamba.py:294-301 on channel-first planes): x_cf (B, D, L) ->
+    y_cf (B, D, L).  Same values; the backward adds the scan's per-direction input gradients and the projection's inside the
+    depthwise conv's backward kernel instead of a pair-sum kernel plus an accumulating GEMM."""
+    _need_hip(x_cf, z_cf)
+    D = x_cf.shape[1]
+    if (A_logs.shape != (4 * D, 16) or x_proj_weight.shape[0] != 4 or x_proj_weight.shape[2] != D
+            or dt_projs_weight.shape[:2] != (4, D) or dt_projs_bias.shape != (4, D) or Ds.shape != (4 * D,)
+            or x_proj_weight.shape[1] != dt_projs_weight.shape[2] + 32 or tuple(conv_weight.shape) != (D, 1, 3, 3)):
+        raise NotImplementedError("ss2d_conv_core: expects 4 directions, d_state 16, a (D,1,3,3) depthwise kernel")
+    return SS2DCoreFn.apply(x_cf, conv_weight, conv_bias, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds, z_cf,
+                            ln_w, ln_b, H, W, eps, prescan_event)
 
 
 class BlockSplitFn(torch.autograd.Function):

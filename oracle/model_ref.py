@@ -201,6 +201,13 @@ def ss2d_core_ref(u2, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds,
     return n * F.silu(z_cf)
 
 
+def ss2d_conv_core_ref(x_cf, conv_weight, conv_bias, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds, z_cf, ln_w,
+                       ln_b, H, W, eps=1e-5, prescan_event=None):
+    """Test double for medmamba_amd.ops.ss2d_conv_core: dwconv_silu_cross_ref followed by ss2d_core_ref."""
+    u2 = dwconv_silu_cross_ref(x_cf, conv_weight, conv_bias, H, W)
+    return ss2d_core_ref(u2, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds, z_cf, ln_w, ln_b, H, W, eps)
+
+
 def block_split_ref(inp, gamma, beta, eps):
     """Test double for medmamba_amd.ops.block_split: chunk + permute + ln_1 exactly as MedMamba.py:350-352."""
     left, right = inp.chunk(2, dim=-1)

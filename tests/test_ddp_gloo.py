@@ -22,8 +22,10 @@ def _build_model():
     from oracle.scan_ref import c_cross_scan_fn, c_selective_scan_fn
     M.selective_scan_fn = c_selective_scan_fn          # test doubles; the product has no CPU scan
     M.cross_scan_fn = c_cross_scan_fn
-    from oracle.model_ref import block_split_ref, dwconv_silu_cross_ref, in_proj_cf_ref, shuffle_residual_ref, ss2d_core_ref
+    from oracle.model_ref import (block_split_ref, dwconv_silu_cross_ref, in_proj_cf_ref, shuffle_residual_ref,
+                                  ss2d_conv_core_ref, ss2d_core_ref)
     M.shuffle_residual, M.dwconv_silu_cross, M.ss2d_core = shuffle_residual_ref, dwconv_silu_cross_ref, ss2d_core_ref
+    M.ss2d_conv_core = ss2d_conv_core_ref
     M.block_split, M.in_proj_cf = block_split_ref, in_proj_cf_ref
     torch.manual_seed(7)
     net = M.VSSM(num_classes=3, depths=[1, 1], dims=[16, 32], drop_path_rate=0.0)
@@ -64,7 +66,8 @@ def test_ddp_gradients_match_single_process(tmp_path, monkeypatch, mode):
     """mode "flat": medmamba_amd.ddp.GradSync (one all-reduce after backward, what bench.py uses);
     mode "torch": DistributedDataParallel through wrap_ddp."""
     from medmamba_amd import modules as M
-    for name in ("selective_scan_fn", "cross_scan_fn", "shuffle_residual", "dwconv_silu_cross", "ss2d_core", "block_split", "in_proj_cf"):
+    for name in ("selective_scan_fn", "cross_scan_fn", "shuffle_residual", "dwconv_silu_cross", "ss2d_core", "ss2d_conv_core",
+                 "block_split", "in_proj_cf"):
         monkeypatch.setattr(M, name, getattr(M, name))      # restore the product functions after this test
     world, port = 2, _free_port()
     mp.spawn(_worker, args=(world, port, str(tmp_path), mode), nprocs=world, join=True)

@@ -181,3 +181,39 @@ def test_block_split_forward_backward(shape):
     l3, r3, _ = block_split_ref(ri2, gamma, beta, 1e-5)
     torch.autograd.backward([l3, r3], [dl, dr])
     assert close(di2.grad, ri2.grad, 2e-5)
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 5, 7, 1), (1, 24, 14, 14, 2), (2, 16, 9, 4, 3), (1, 160, 6, 6, 5)])
+def test_ss2d_conv_core_forward_backward(shape, layout):
+    """depthwise conv + SiLU + projections + scan + merge + out_norm + gate as ONE Function (the backward folds the scan's
+    per-direction input gradients and the projection's into the conv's backward kernel) vs the oracle chain."""
+    from medmamba_amd.ops import ss2d_conv_core
+    from oracle.model_ref import ss2d_conv_core_ref
+    B, D, H, W, R = shape
+    L, N = H * W, 16
+    g = torch.Generator().manual_seed(sum(shape) + 1)
+    mk = lambda *s: torch.randn(*s, generator=g)
+    x = mk(B, D, L)
+    cw, cb = mk(D, 1, 3, 3) * 0.5, mk(D) * 0.2
+    Wx, Wdt = mk(4, R + 2 * N, D) / D ** 0.5, mk(4, D, R) / R ** 0.5
+    A_logs = mk(4 * D, N) * 0.5
+    Dp, dbias = mk(4 * D), mk(4, D) - 3
+    z, lw, lb = mk(B, D, L), 1 + 0.1 * mk(D), 0.1 * mk(D)
+    dy = mk(B, D, L)
+    leaves = (x, cw, cb, Wx, Wdt, dbias, A_logs, Dp, z, lw, lb)
+    ref_in = [t.clone().requires_grad_() for t in leaves]
+    ref = ss2d_conv_core_ref(*ref_in, H, W, 1e-5)
+    ref.backward(dy)
+    dev_in = [t.to(DEV).requires_grad_() for t in leaves]
+    if layout == "cm":
+        out = ss2d_conv_core(_cm(dev_in[0]), *dev_in[1:8], _cm(dev_in[8]), *dev_in[9:], H, W, 1e-5)
+        out.backward(_cm(dy.to(DEV)))
+    else:
+        out = ss2d_conv_core(*dev_in, H, W, 1e-5)
+        out.backward(dy.to(DEV))
+    err = (out.detach().cpu() - ref.detach()).abs().max().item()
+    assert err <= 5e-5 * max(1.0, ref.detach().abs().max().item()), err
+    names = ["dx", "dconv_w", "dconv_b", "dWx", "dWdt", "dbias", "dA_logs", "dD", "dz", "dln_w", "dln_b"]
+    for n, a, b in zip(names, dev_in, ref_in):
+        e = (a.grad.cpu() - b.grad).abs().max().item() / max(1.0, b.grad.abs().max().item())
+        assert e <= 5e-4, (n, e)

@@ -11,7 +11,7 @@ import torch
 from conftest import GOLDEN, load_golden, split_sd
 from medmamba_amd import modules as M
 from oracle.model_ref import (block_split_ref, dwconv_silu_cross_ref, in_proj_cf_ref, shuffle_residual_ref,
-                              ss2d_core_ref)
+                              ss2d_conv_core_ref, ss2d_core_ref)
 from oracle.scan_ref import c_cross_scan_fn, c_selective_scan_fn
 
 
@@ -22,6 +22,7 @@ def oracle_scan(monkeypatch):
     monkeypatch.setattr(M, "shuffle_residual", shuffle_residual_ref)
     monkeypatch.setattr(M, "dwconv_silu_cross", dwconv_silu_cross_ref)
     monkeypatch.setattr(M, "ss2d_core", ss2d_core_ref)
+    monkeypatch.setattr(M, "ss2d_conv_core", ss2d_conv_core_ref)
     monkeypatch.setattr(M, "block_split", block_split_ref)
     monkeypatch.setattr(M, "in_proj_cf", in_proj_cf_ref)
 
