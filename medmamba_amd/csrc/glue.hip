@@ -748,18 +748,23 @@ __global__ __launch_bounds__(256) void ss2d_pack_kernel(const float* __restrict_
                                                         const float* __restrict__ s2, const float* __restrict__ s3,
                                                         const float* __restrict__ s4, float* __restrict__ dst, int D, int C,
                                                         int R, int N, PackGrid pg) {
-  const PackSeg L = pack_layout(D, C, R, N);
+  // no runtime-indexed local arrays here: they would live in scratch memory, and a dispatch that needs scratch costs
+  // ~12 us of set-up on top of a 2 us kernel (measured)
   const int b = blockIdx.x;
-  int seg = 0;
-#pragma unroll
-  for (int q = 1; q < 5; ++q) seg += b >= pg.blk_off[q];
-  const int lb = b - pg.blk_off[seg], nbs = pg.nb[seg];
+  const int seg = (b >= pg.blk_off[1]) + (b >= pg.blk_off[2]) + (b >= pg.blk_off[3]) + (b >= pg.blk_off[4]);
+  const int boff = seg == 0 ? pg.blk_off[0] : seg == 1 ? pg.blk_off[1] : seg == 2 ? pg.blk_off[2] : seg == 3 ? pg.blk_off[3] : pg.blk_off[4];
+  const int nbs = seg == 0 ? pg.nb[0] : seg == 1 ? pg.nb[1] : seg == 2 ? pg.nb[2] : seg == 3 ? pg.nb[3] : pg.nb[4];
+  const int pd = seg == 0 ? C * D : seg == 1 ? D * R : seg == 2 ? D * N : D;
+  const int al = 63;
+  const int o1 = (4 * C * D + al) & ~al, o2 = (o1 + 4 * D * R + al) & ~al, o3 = (o2 + 4 * D * N + al) & ~al,
+            o4 = (o3 + 4 * D + al) & ~al;
+  const int soff = seg == 0 ? 0 : seg == 1 ? o1 : seg == 2 ? o2 : seg == 3 ? o3 : o4;      // == pack_layout().off[seg]
+  const int lb = b - boff;
   const int g = lb / nbs, chunk = lb - g * nbs;            // wave-uniform
-  const int pd = L.per_dir[seg];
   const int rem = chunk * 256 + threadIdx.x;
   if (rem >= pd) return;
   const int k = ((g & 1) << 1) | (g >> 1);                 // reference direction of kernel direction g (an involution)
-  const int i = L.off[seg] + g * pd + rem;                 // packed index (kernel order)
+  const int i = soff + g * pd + rem;                       // packed index (kernel order)
   const int j = k * pd + rem;                              // index inside the segment, reference direction order
   if constexpr (!BWD) {
     const float* src = seg == 0 ? s0 : seg == 1 ? s1 : seg == 2 ? s3 : seg == 3 ? s4 : s2;   // (Wx, Wdt, bias, A_logs, Ds)
@@ -767,7 +772,7 @@ __global__ __launch_bounds__(256) void ss2d_pack_kernel(const float* __restrict_
     dst[i] = seg == 2 ? -expf(v) : v;
   } else {
     // s0 = dP (packed), s1 = P (packed): d(A_logs) = dA * A
-    dst[L.off[seg] + j] = s0[i] * (seg == 2 ? s1[i] : 1.0f);
+    dst[soff + j] = s0[i] * (seg == 2 ? s1[i] : 1.0f);
   }
 }
 

@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Diagnostic: time of mm_ss2d_pack_fwd / _bwd alone, per MedMamba-S stage."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from medmamba_amd import _lib
+dev = torch.device("cuda:0"); lib = _lib.lib()
+for D, R in [(96, 3), (192, 6), (384, 12), (768, 24)]:
+    N, C = 16, R + 32
+    n = lib.mm_ss2d_pack_size(D, C, R, N)
+    srcs = [torch.randn(4, C, D, device=dev), torch.randn(4, D, R, device=dev), torch.randn(4, D, device=dev),
+            torch.randn(4 * D, N, device=dev), torch.randn(4 * D, device=dev)]
+    P = torch.empty(n, device=dev); G = torch.empty(n, device=dev); dP = torch.randn(n, device=dev)
+    st = _lib.raw_stream()
+    def f(): lib.mm_ss2d_pack_fwd(*[t.data_ptr() for t in srcs], P.data_ptr(), D, C, R, N, st)
+    def b(): lib.mm_ss2d_pack_bwd(dP.data_ptr(), P.data_ptr(), G.data_ptr(), D, C, R, N, st)
+    for fn, name in ((f, "fwd"), (b, "bwd")):
+        for _ in range(5): fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(200): fn()
+        e1.record(); torch.cuda.synchronize()
+        print(f"D={D} n={n} {name}: {e0.elapsed_time(e1) / 200 * 1e3:.2f} us per launch (back to back)")
+    def c(): G.copy_(dP)
+    for _ in range(5): c()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(200): c()
+    e1.record(); torch.cuda.synchronize()
+    print(f"D={D} n={n} torch copy_: {e0.elapsed_time(e1) / 200 * 1e3:.2f} us per launch")
