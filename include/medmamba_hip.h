@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MM_ABI_VERSION 8
+#define MM_ABI_VERSION 9
 
 enum mm_status {
   MM_OK = 0,
@@ -162,7 +162,7 @@ int mm_plane_transpose(const float* src, int64_t src_sb, int64_t src_sd, float* 
 /* out_norm LayerNorm over the D channels (eps) + gate with SiLU(z) (MedMamba.py:300-301), channel-first:
  *   y[b,d,p] = ((m[b,d,p]-mu[b,p])*rstd[b,p]*gamma[d]+beta[d]) * silu(z[b,d,p]);  m,y (batch,D,L); z planes with batch
  *   stride z_sb; mu,rstd (batch,L) outputs.  Backward: dm (batch stride dm_sb), dz (batch stride dz_sb) and per-wave
- *   partial sums ws[row*2*D + (0: dgamma, D: dbeta) + d] for row < mm_ln_gate_rows(batch, L) (the caller sums rows). */
+ *   partial sums ws[row*2*D + (0: dgamma, D: dbeta) + d] for row < mm_ln_gate_rows(batch, D, L) (the caller sums rows). */
 int mm_ln_gate_fwd(const float* m, int64_t m_sb, int64_t m_sd, const float* z, int64_t z_sb, int64_t z_sd, const float* gamma,
                    const float* beta, float eps, float* y, int64_t y_sb, int64_t y_sd, float* mu, float* rstd, int batch, int D,
                    int L, void* stream);
@@ -170,7 +170,7 @@ int mm_ln_gate_bwd(const float* dy, int64_t dy_sb, int64_t dy_sd, const float* m
                    int64_t z_sb, int64_t z_sd, const float* gamma, const float* beta, const float* mu, const float* rstd,
                    float* dm, int64_t dm_sb, int64_t dm_sd, float* dz, int64_t dz_sb, int64_t dz_sd, float* ws, int batch,
                    int D, int L, void* stream);
-int mm_ln_gate_rows(int batch, int L);
+int mm_ln_gate_rows(int batch, int D, int L);
 
 /* Block prologue of SS_Conv_SSM.forward (MedMamba.py:350-352): inp (batch, P, 2*C2) NHWC ->
  *   left_nchw (batch, C2, P) = inp[..., :C2] transposed (conv-branch input, replaces chunk + permute + contiguous)

@@ -6,6 +6,7 @@
 //     out[b,p,2i+1] = ssm[b,p,i]  + inp[b,p,2i+1]      ssm : SS2D-branch output, NHWC (b, P, C/2) or channel-first (b, C/2, P)
 //   The NCHW->NHWC transpose of `left` goes through a 32x33 LDS tile; all global accesses are 128-B runs.
 //   The backward is the same permutation read the other way (d_left, d_ssm from dout; d_inp = dout).
+#include <cstdlib>
 #include "mm_common.h"
 #include "medmamba_hip.h"
 
@@ -428,6 +429,175 @@ inline int pick_pw(int batch, int L) {   // positions per wave: fewer when there
   if (npos >= 16 * 1024) return 16;
   return 4;
 }
+
+// ---- single-pass variants: the CPL channels a lane owns stay in registers between the statistics and the output pass,
+// so every operand crosses HBM once (the two-pass kernels above re-read m / dy / z: their working set, 3 x 77 MB at the
+// 56x56 stage, does not survive in L2).  TPP = 64/PW lanes share a position; CPL >= ceil(D / TPP).
+template <int PW, int CPL>
+__global__ __launch_bounds__(256) void ln_gate_fwd1_kernel(const float* __restrict__ m, int64_t m_sb, int64_t m_sd,
+                                                           const float* __restrict__ z, int64_t z_sb, int64_t z_sd,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           float eps, float* __restrict__ y, int64_t y_sb, int64_t y_sd,
+                                                           float* __restrict__ mu_out, float* __restrict__ rstd_out, int D,
+                                                           int L, int npos_blocks) {
+  constexpr int TPP = 64 / PW;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int b = blockIdx.x / npos_blocks, pb = blockIdx.x % npos_blocks;
+  const int p = (pb * 4 + wv) * PW + (lane % PW);
+  const int ck = lane / PW;
+  const bool ok = p < L;
+  const float* mp = m + (int64_t)b * m_sb + p;
+  const float* zp = z + (int64_t)b * z_sb + p;
+  float mv[CPL], s1 = 0.f;
+#pragma unroll
+  for (int k = 0; k < CPL; ++k) {
+    const int d = ck + k * TPP;
+    mv[k] = (ok && d < D) ? mp[d * m_sd] : 0.f;
+    s1 += mv[k];
+  }
+  const float mu = pos_sum<PW>(s1) / D;
+  float s2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < CPL; ++k) {
+    const float dv = (ck + k * TPP < D) ? mv[k] - mu : 0.f;
+    s2 = fmaf(dv, dv, s2);
+  }
+  const float rstd = __builtin_amdgcn_rsqf(pos_sum<PW>(s2) / D + eps);
+  if (!ok) return;
+  if (ck == 0) {
+    mu_out[(int64_t)b * L + p] = mu;
+    rstd_out[(int64_t)b * L + p] = rstd;
+  }
+  float* yp = y + (int64_t)b * y_sb + p;
+#pragma unroll
+  for (int k = 0; k < CPL; ++k) {
+    const int d = ck + k * TPP;
+    if (d < D) {
+      const float n = (mv[k] - mu) * rstd * gamma[d] + beta[d];
+      const float zz = zp[d * z_sd];
+      yp[d * y_sd] = n * (zz * sigmoid_f(zz));
+    }
+  }
+}
+
+template <int PW, int CPL>
+__global__ __launch_bounds__(256) void ln_gate_bwd1_kernel(const float* __restrict__ dy, int64_t g_sb, int64_t g_sd,
+                                                           const float* __restrict__ m, int64_t m_sb, int64_t m_sd,
+                                                           const float* __restrict__ z, int64_t z_sb, int64_t z_sd,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           const float* __restrict__ mu_in, const float* __restrict__ rstd_in,
+                                                           float* __restrict__ dm, int64_t dm_sb, int64_t dm_sd,
+                                                           float* __restrict__ dz, int64_t dz_sb, int64_t dz_sd,
+                                                           float* __restrict__ ws, int D, int L, int npos_blocks) {
+  constexpr int TPP = 64 / PW;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int b = blockIdx.x / npos_blocks, pb = blockIdx.x % npos_blocks;
+  const int p = (pb * 4 + wv) * PW + (lane % PW);
+  const int ck = lane / PW;
+  const bool ok = p < L;
+  const float* mp = m + (int64_t)b * m_sb + p;
+  const float* gp = dy + (int64_t)b * g_sb + p;
+  const float* zp = z + (int64_t)b * z_sb + p;
+  const float mu = ok ? mu_in[(int64_t)b * L + p] : 0.f, rstd = ok ? rstd_in[(int64_t)b * L + p] : 0.f;
+  float gv[CPL], zv[CPL], xh[CPL], c1 = 0.f, c2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < CPL; ++k) {
+    const int d = ck + k * TPP;
+    const bool in = ok && d < D;
+    zv[k] = in ? zp[d * z_sd] : 0.f;
+    gv[k] = in ? gp[d * g_sd] : 0.f;
+    xh[k] = in ? (mp[d * m_sd] - mu) * rstd : 0.f;
+    const float dn = in ? gv[k] * (zv[k] * sigmoid_f(zv[k])) * gamma[d] : 0.f;
+    c1 += dn;
+    c2 = fmaf(dn, xh[k], c2);
+  }
+  c1 = pos_sum<PW>(c1) / D;
+  c2 = pos_sum<PW>(c2) / D;
+  float* dmp = dm + (int64_t)b * dm_sb + p;
+  float* dzp = dz + (int64_t)b * dz_sb + p;
+  float* wrow = ws + ((int64_t)blockIdx.x * 4 + wv) * 2 * D;
+#pragma unroll
+  for (int k = 0; k < CPL; ++k) {
+    const int d = ck + k * TPP;
+    float pg = 0.f, pb_ = 0.f;
+    if (ok && d < D) {
+      const float zz = zv[k], s_ = sigmoid_f(zz), sz = zz * s_;
+      const float gm = gamma[d];
+      const float n = xh[k] * gm + beta[d];
+      const float dn = gv[k] * sz;
+      dzp[d * dz_sd] = gv[k] * n * (s_ * (1.f + zz * (1.f - s_)));
+      dmp[d * dm_sd] = rstd * (dn * gm - c1 - xh[k] * c2);
+      pg = dn * xh[k];
+      pb_ = dn;
+    }
+    // sum over the PW positions of this wave that share channel d (lanes with equal ck): xor over the low bits
+#pragma unroll
+    for (int s_ = 1; s_ < PW; s_ <<= 1) {
+      pg += __shfl_xor(pg, s_);
+      pb_ += __shfl_xor(pb_, s_);
+    }
+    if ((lane % PW) == 0 && d < D) {
+      wrow[d] = pg;
+      wrow[D + d] = pb_;
+    }
+  }
+}
+
+// plan of the LayerNorm + gate kernels: positions per wave and, for the single-pass kernels, channels per lane
+// (cpl = 0: D is too wide for the register-resident form -> two-pass kernels)
+struct LnPlan { int pw, cpl; };
+inline LnPlan plan_ln(int batch, int D, int L, bool bwd) {
+  const int tpp = D <= 128 ? 4 : 16;
+  const int need = (D + tpp - 1) / tpp;
+  LnPlan pl;
+  // the backward keeps three values per channel: 48 channels per lane would be 256 VGPRs (1 wave per SIMD)
+  static const int two_pass = [] { const char* e = getenv("MM_LN_TWO_PASS"); return e ? atoi(e) : 0; }();   // tuning knob: 1 = fwd, 2 = bwd, 3 = both
+  // measured (tools/bench_ln_gate.py, B = 64): forward 86 -> 48 / 39 -> 36 / 40 -> 31 / 38 -> 27 us for the four S stages;
+  // backward only wins where 16 lanes share a position and still own <= 24 channels (D = 384: 80 -> 55 us) — with 4
+  // lanes per position it writes 4x the partial-sum rows (165 -> 158 us at D = 96, 60 -> 70 us at D = 192)
+  const bool fits = bwd ? (tpp == 16 && need > 16 && need <= 24) : need <= 48;
+  if (fits && !(two_pass & (bwd ? 2 : 1))) {
+    pl.pw = 64 / tpp;
+    pl.cpl = need <= 8 ? 8 : need <= 16 ? 16 : need <= 24 ? 24 : need <= 32 ? 32 : 48;
+  } else {
+    pl.pw = pick_pw(batch, L);
+    pl.cpl = 0;
+  }
+  return pl;
+}
+
+template <int PW>
+int launch_ln_fwd1(int cpl, dim3 grid, hipStream_t s, const float* m, int64_t m_sb, int64_t m_sd, const float* z, int64_t z_sb,
+                   int64_t z_sd, const float* gamma, const float* beta, float eps, float* y, int64_t y_sb, int64_t y_sd, float* mu,
+                   float* rstd, int D, int L, int npb) {
+#define MM_LN_FWD1(CPL_) hipLaunchKernelGGL((ln_gate_fwd1_kernel<PW, CPL_>), grid, dim3(256), 0, s, m, m_sb, m_sd, z, z_sb, z_sd, \
+                                            gamma, beta, eps, y, y_sb, y_sd, mu, rstd, D, L, npb)
+  switch (cpl) {
+    case 8: MM_LN_FWD1(8); break;
+    case 16: MM_LN_FWD1(16); break;
+    case 24: MM_LN_FWD1(24); break;
+    case 32: MM_LN_FWD1(32); break;
+    default: MM_LN_FWD1(48); break;
+  }
+#undef MM_LN_FWD1
+  return (int)hipGetLastError();
+}
+
+template <int PW>
+int launch_ln_bwd1(int cpl, dim3 grid, hipStream_t s, const float* dy, int64_t dy_sb, int64_t dy_sd, const float* m, int64_t m_sb,
+                   int64_t m_sd, const float* z, int64_t z_sb, int64_t z_sd, const float* gamma, const float* beta, const float* mu,
+                   const float* rstd, float* dm, int64_t dm_sb, int64_t dm_sd, float* dz, int64_t dz_sb, int64_t dz_sd, float* ws,
+                   int D, int L, int npb) {
+#define MM_LN_BWD1(CPL_) hipLaunchKernelGGL((ln_gate_bwd1_kernel<PW, CPL_>), grid, dim3(256), 0, s, dy, dy_sb, dy_sd, m, m_sb, m_sd, \
+                                            z, z_sb, z_sd, gamma, beta, mu, rstd, dm, dm_sb, dm_sd, dz, dz_sb, dz_sd, ws, D, L, npb)
+  switch (cpl) {
+    case 8: MM_LN_BWD1(8); break;
+    case 16: MM_LN_BWD1(16); break;
+    default: MM_LN_BWD1(24); break;
+  }
+#undef MM_LN_BWD1
+  return (int)hipGetLastError();
+}
 }  // namespace
 
 extern "C" {
@@ -477,8 +647,8 @@ int mm_plane_transpose(const float* src, int64_t src_sb, int64_t src_sd, float* 
   return (int)hipGetLastError();
 }
 
-int mm_ln_gate_rows(int batch, int L) {   // rows of the dgamma/dbeta workspace written by mm_ln_gate_bwd
-  const int pw = pick_pw(batch, L);
+int mm_ln_gate_rows(int batch, int D, int L) {   // rows of the dgamma/dbeta workspace written by mm_ln_gate_bwd
+  const int pw = plan_ln(batch, D, L, true).pw;
   return batch * ((L + 4 * pw - 1) / (4 * pw)) * 4;
 }
 
@@ -487,9 +657,14 @@ int mm_ln_gate_fwd(const float* m, int64_t m_sb, int64_t m_sd, const float* z, i
                    int L, void* stream) {
   if (!m || !z || !gamma || !beta || !y || !mu || !rstd) return MM_ERR_NULL;
   if (batch <= 0 || D <= 0 || L <= 0) return MM_ERR_SHAPE;
-  const int pw = pick_pw(batch, L), npb = (L + 4 * pw - 1) / (4 * pw);
+  const LnPlan pl = plan_ln(batch, D, L, false);
+  const int pw = pl.pw, npb = (L + 4 * pw - 1) / (4 * pw);
   const dim3 grid(batch * npb), blk(256);
   hipStream_t s = (hipStream_t)stream;
+  if (pl.cpl > 0) {
+    return pw == 16 ? launch_ln_fwd1<16>(pl.cpl, grid, s, m, m_sb, m_sd, z, z_sb, z_sd, gamma, beta, eps, y, y_sb, y_sd, mu, rstd, D, L, npb)
+                    : launch_ln_fwd1<4>(pl.cpl, grid, s, m, m_sb, m_sd, z, z_sb, z_sd, gamma, beta, eps, y, y_sb, y_sd, mu, rstd, D, L, npb);
+  }
   if (pw == 64) hipLaunchKernelGGL(ln_gate_fwd_kernel<64>, grid, blk, 0, s, m, m_sb, m_sd, z, z_sb, z_sd, gamma, beta, eps, y, y_sb, y_sd, mu, rstd, D, L, npb);
   else if (pw == 16) hipLaunchKernelGGL(ln_gate_fwd_kernel<16>, grid, blk, 0, s, m, m_sb, m_sd, z, z_sb, z_sd, gamma, beta, eps, y, y_sb, y_sd, mu, rstd, D, L, npb);
   else hipLaunchKernelGGL(ln_gate_fwd_kernel<4>, grid, blk, 0, s, m, m_sb, m_sd, z, z_sb, z_sd, gamma, beta, eps, y, y_sb, y_sd, mu, rstd, D, L, npb);
@@ -502,9 +677,14 @@ int mm_ln_gate_bwd(const float* dy, int64_t dy_sb, int64_t dy_sd, const float* m
                    int D, int L, void* stream) {
   if (!dy || !m || !z || !gamma || !beta || !mu || !rstd || !dm || !dz || !ws) return MM_ERR_NULL;
   if (batch <= 0 || D <= 0 || L <= 0) return MM_ERR_SHAPE;
-  const int pw = pick_pw(batch, L), npb = (L + 4 * pw - 1) / (4 * pw);
+  const LnPlan pl = plan_ln(batch, D, L, true);
+  const int pw = pl.pw, npb = (L + 4 * pw - 1) / (4 * pw);
   const dim3 grid(batch * npb), blk(256);
   hipStream_t s = (hipStream_t)stream;
+  if (pl.cpl > 0) {
+    return pw == 16 ? launch_ln_bwd1<16>(pl.cpl, grid, s, dy, dy_sb, dy_sd, m, m_sb, m_sd, z, z_sb, z_sd, gamma, beta, mu, rstd, dm, dm_sb, dm_sd, dz, dz_sb, dz_sd, ws, D, L, npb)
+                    : launch_ln_bwd1<4>(pl.cpl, grid, s, dy, dy_sb, dy_sd, m, m_sb, m_sd, z, z_sb, z_sd, gamma, beta, mu, rstd, dm, dm_sb, dm_sd, dz, dz_sb, dz_sd, ws, D, L, npb);
+  }
   if (pw == 64) hipLaunchKernelGGL(ln_gate_bwd_kernel<64>, grid, blk, 0, s, dy, dy_sb, dy_sd, m, m_sb, m_sd, z, z_sb, z_sd, gamma, beta, mu, rstd, dm, dm_sb, dm_sd, dz, dz_sb, dz_sd, ws, D, L, npb);
   else if (pw == 16) hipLaunchKernelGGL(ln_gate_bwd_kernel<16>, grid, blk, 0, s, dy, dy_sb, dy_sd, m, m_sb, m_sd, z, z_sb, z_sd, gamma, beta, mu, rstd, dm, dm_sb, dm_sd, dz, dz_sb, dz_sd, ws, D, L, npb);
   else hipLaunchKernelGGL(ln_gate_bwd_kernel<4>, grid, blk, 0, s, dy, dy_sb, dy_sd, m, m_sb, m_sd, z, z_sb, z_sd, gamma, beta, mu, rstd, dm, dm_sb, dm_sd, dz, dz_sb, dz_sd, ws, D, L, npb);

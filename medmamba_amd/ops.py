@@ -342,7 +342,7 @@ class SS2DCoreFn(torch.autograd.Function):
         dout2 = _planes(Bsz, 2 * D, L, dev, cm)         # channel block 0: dm, block 1: its plane transpose
         dz = _planes(Bsz, D, L, dev, cm)
         lib = _lib.lib()
-        ws = torch.empty((lib.mm_ln_gate_rows(Bsz, L), 2 * D), device=dev, dtype=torch.float32)
+        ws = torch.empty((lib.mm_ln_gate_rows(Bsz, D, L), 2 * D), device=dev, dtype=torch.float32)
         with _lib.device_guard(dev):
             rc = lib.mm_ln_gate_bwd(*_pl(dy), *_pl(m), *_pl(z_cf), ln_w.data_ptr(), ln_b.data_ptr(), mu.data_ptr(),
                                     rstd.data_ptr(), *_pl(dout2), *_pl(dz), ws.data_ptr(), Bsz, D, L, _stream())

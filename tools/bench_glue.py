@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Diagnostic: every glue op alone per MedMamba-S stage (B = 64): time, bytes moved, achieved GB/s."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from medmamba_amd import ops
+dev = torch.device("cuda:0")
+B = 64
+def t(fn, it=30):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(it): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / it * 1e3
+for C, hw in [(96, 56), (192, 28), (384, 14), (768, 7)]:
+    L = hw * hw; D = C; dm = C // 2; unit = B * D * L * 4 / 1e6       # MB of one (B, D, L) plane set
+    r = lambda *s: torch.randn(*s, device=dev)
+    cm = ops.channel_major(B, L)
+    pl = lambda d: ops._planes(B, d, L, dev, cm).normal_()
+    rows = []
+    inp = r(B, hw, hw, C).requires_grad_(); g, b_ = r(dm), r(dm)
+    left, rn, res = ops.block_split(inp, g, b_, 1e-5)
+    rows.append(("block_split fwd", t(lambda: ops.block_split(inp, g, b_, 1e-5)), 1.0 * unit))          # read C, write C/2 + C/2
+    gl, gr, gres = torch.randn_like(left), torch.randn_like(rn), torch.randn_like(res)
+    rows.append(("block_split bwd", t(lambda: torch.autograd.grad([left, rn, res], inp, [gl, gr, gres], retain_graph=True)), 2.5 * unit))
+    x = pl(D).requires_grad_(); w, bb = r(D, 1, 3, 3).requires_grad_(), r(D).requires_grad_()
+    u2 = ops.dwconv_silu_cross(x, w, bb, hw, hw)
+    rows.append(("dwconv fwd", t(lambda: ops.dwconv_silu_cross(x, w, bb, hw, hw)), 3 * unit))
+    gu = pl(2 * D)
+    rows.append(("dwconv bwd", t(lambda: torch.autograd.grad(u2, x, gu, retain_graph=True)), 4 * unit))
+    lft = r(B, dm, hw, hw); ssm = pl(dm); xin = r(B, hw, hw, C)
+    rows.append(("shuffle_residual fwd", t(lambda: ops.shuffle_residual(lft, ssm, xin, True)), 2 * unit))
+    for name, us, mb in rows:
+        print(f"C={C:4d} L={L:5d} {name:<22} {us:8.1f} us  {mb:8.1f} MB  {mb / us * 1e3:8.0f} GB/s")
