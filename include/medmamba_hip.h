@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MM_ABI_VERSION 9
+#define MM_ABI_VERSION 10
 
 enum mm_status {
   MM_OK = 0,
@@ -195,6 +195,12 @@ int mm_ss2d_pack_size(int D, int C, int R, int N);
 int mm_ss2d_pack_fwd(const float* x_proj_w, const float* dt_w, const float* dt_b, const float* A_logs, const float* Ds,
                      float* packed, int D, int C, int R, int N, void* stream);
 int mm_ss2d_pack_bwd(const float* dpacked, const float* packed, float* grads, int D, int C, int R, int N, void* stream);
+
+/* Bias gradient of the conv branch's convolutions (MedMamba.py:338-346): out[c] = sum over batch and positions of the
+ * contiguous NCHW tensor x (batch, C, HW).  When mm_channel_sum_nchw_split(batch, C) > 1 the batch is split over several
+ * workgroups per channel that add with atomics: the caller zero-fills out (C floats) first. */
+int mm_channel_sum_nchw_split(int batch, int C);
+int mm_channel_sum_nchw(const float* x, float* out, int batch, int C, int HW, void* stream);
 
 int mm_abi_version(void);
 const char* mm_status_string(int status);

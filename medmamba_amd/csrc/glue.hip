@@ -992,3 +992,71 @@ int mm_ss2d_pack_bwd(const float* dpacked, const float* packed, float* grads, in
 }
 
 }  // extern "C"
+
+// =====================================================================================================
+// Per-channel sum of an NCHW tensor: out[c] = sum_{b,p} x[b,c,p]  — the bias gradient of the conv branch's
+// convolutions (MedMamba.py:338-346).  ATen's generic reduction runs this at ~0.65 TB/s (59 us for 64x48x56x56);
+// here one workgroup streams one channel (float4 loads, LDS tree), a second grid dimension splits the batch when
+// there are fewer channels than CUs (partials then go through fp32 atomics into a zero-filled out).
+// =====================================================================================================
+namespace {
+template <bool VEC, bool ATOMIC>
+__global__ __launch_bounds__(512) void channel_sum_nchw_kernel(const float* __restrict__ x, float* __restrict__ out, int batch,
+                                                               int C, int HW, int bsplit) {
+  __shared__ float red[8];
+  const int c = blockIdx.x, part = blockIdx.y;
+  const int b0 = (int)((int64_t)batch * part / bsplit), b1 = (int)((int64_t)batch * (part + 1) / bsplit);
+  float acc = 0.f;
+  for (int b = b0; b < b1; ++b) {
+    const float* p = x + ((int64_t)b * C + c) * HW;
+    if constexpr (VEC) {
+      const float4* p4 = reinterpret_cast<const float4*>(p);
+      for (int i = threadIdx.x; i < HW / 4; i += blockDim.x) {
+        const float4 v = p4[i];
+        acc += (v.x + v.y) + (v.z + v.w);
+      }
+    } else {
+      for (int i = threadIdx.x; i < HW; i += blockDim.x) acc += p[i];
+    }
+  }
+  acc = mm::group_sum<16>(acc);
+  acc += __shfl_xor(acc, 16);
+  acc += __shfl_xor(acc, 32);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) red[wv] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int j = 0; j < (int)(blockDim.x >> 6); ++j) t += red[j];
+    if constexpr (ATOMIC) atomicAdd(out + c, t); else out[c] = t;
+  }
+}
+}  // namespace
+
+extern "C" {
+
+int mm_channel_sum_nchw_split(int batch, int C) {      // > 1: the caller must zero-fill `out` (atomics)
+  int s = 1;
+  while (C * s < 256 && s * 2 <= batch && s < 16) s *= 2;
+  return s;
+}
+
+int mm_channel_sum_nchw(const float* x, float* out, int batch, int C, int HW, void* stream) {
+  if (!x || !out) return MM_ERR_NULL;
+  if (batch <= 0 || C <= 0 || HW <= 0) return MM_ERR_SHAPE;
+  const int split = mm_channel_sum_nchw_split(batch, C);
+  const bool vec = (HW % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+  const int nt = HW >= 2048 ? 512 : (HW >= 256 ? 256 : 64);
+  const dim3 grid(C, split), blk(nt);
+  hipStream_t s = (hipStream_t)stream;
+  if (split > 1) {
+    if (vec) hipLaunchKernelGGL((channel_sum_nchw_kernel<true, true>), grid, blk, 0, s, x, out, batch, C, HW, split);
+    else hipLaunchKernelGGL((channel_sum_nchw_kernel<false, true>), grid, blk, 0, s, x, out, batch, C, HW, split);
+  } else {
+    if (vec) hipLaunchKernelGGL((channel_sum_nchw_kernel<true, false>), grid, blk, 0, s, x, out, batch, C, HW, split);
+    else hipLaunchKernelGGL((channel_sum_nchw_kernel<false, false>), grid, blk, 0, s, x, out, batch, C, HW, split);
+  }
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"

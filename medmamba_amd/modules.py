@@ -24,7 +24,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 import torch.utils.checkpoint as checkpoint
 
-from .ops import block_split, dwconv_silu_cross, in_proj_cf, out_proj_cf, shuffle_residual, ss2d_conv_core, ss2d_core
+from .ops import (PointwiseConvFn, block_split, conv2d_bias, dwconv_silu_cross, in_proj_cf, out_proj_cf, shuffle_residual,
+                  ss2d_conv_core, ss2d_core)
 from .selective_scan_interface import CROSS_SCAN_K_OF_G, cross_scan_fn, selective_scan_fn
 
 trunc_normal_ = nn.init.trunc_normal_   # timm.layers.trunc_normal_ == torch.nn.init.trunc_normal_
@@ -54,13 +55,15 @@ def _is_pointwise(m):
             and m.dilation == (1, 1) and m.groups == 1 and m.padding_mode == "zeros")
 
 
-def _pointwise_conv(x, weight, bias):
-    """nn.Conv2d(kernel_size=1) on NCHW input as out[b] = W @ x[b] (+ bias): a batched GEMM with a broadcast weight."""
-    B, C, H, W = x.shape
-    w = weight.view(weight.shape[0], C).unsqueeze(0).expand(B, -1, -1)
-    x = x.reshape(B, C, H * W)
-    out = torch.bmm(w, x) if bias is None else torch.baddbmm(bias.view(1, -1, 1), w, x)
-    return out.view(B, -1, H, W)
+def _conv_branch(mods, x):
+    """Run the modules of the conv branch in order; dense convs with a bias go through ops.conv2d_bias (same MIOpen
+    kernels, fast bias gradient), 1x1 convs through PointwiseConvFn (batched GEMM)."""
+    for m in mods:
+        if isinstance(m, nn.Conv2d) and x.is_cuda:
+            x = PointwiseConvFn.apply(x, m.weight, m.bias) if _is_pointwise(m) else conv2d_bias(x, m)
+        else:
+            x = m(x)
+    return x
 
 
 def _side_stream(device):
@@ -346,12 +349,8 @@ class SS_Conv_SSM(nn.Module):
             left, right_n = left.permute(0, 3, 1, 2).contiguous(), self.ln_1(right)
         conv = self.conv33conv33conv11
         fold_relu = isinstance(conv[-1], nn.ReLU)              # the trailing ReLU (:347) is applied by shuffle_residual
-        conv_body = conv[:-1] if fold_relu else conv
-        if fold_relu and _is_pointwise(conv[-2]) and input.is_cuda:
-            # the 1x1 conv (:346) as a batched GEMM on the NCHW planes: MIOpen's weight-gradient for it runs one 64x64
-            # tile per image at the 56x56 stage (0.39 ms per call, measured); hipBLASLt needs 0.04 ms for the same product
-            pw, body = conv[-2], conv[:-2]
-            conv_body = lambda t: _pointwise_conv(body(t), pw.weight, pw.bias)
+        mods = list(conv)[:-1] if fold_relu else list(conv)
+        conv_body = lambda t: _conv_branch(mods, t)
         if _TWO_STREAMS and input.is_cuda:
             # the conv branch and the SS2D branch are independent (MedMamba.py:351-353): run the conv branch on a side
             # HIP stream so that its MIOpen kernels overlap the scan (autograd replays the backward on the same streams)

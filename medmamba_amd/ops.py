@@ -444,6 +444,84 @@ def ss2d_conv_core(x_cf, conv_weight, conv_bias, x_proj_weight, dt_projs_weight,
                             ln_w, ln_b, H, W, eps, prescan_event)
 
 
+def channel_sum_nchw(x):
+    """(B, C, H, W) or (B, C, L) contiguous fp32 -> (C,) sums over batch and positions (a conv's bias gradient)."""
+    _need_hip(x)
+    x = x.float().contiguous()
+    B, C = x.shape[0], x.shape[1]
+    HW = x.numel() // (B * C)
+    lib = _lib.lib()
+    out = (torch.zeros if lib.mm_channel_sum_nchw_split(B, C) > 1 else torch.empty)((C,), device=x.device, dtype=torch.float32)
+    with _lib.device_guard(x.device):
+        rc = lib.mm_channel_sum_nchw(x.data_ptr(), out.data_ptr(), B, C, HW, _stream())
+    _lib.check(rc, "mm_channel_sum_nchw")
+    return out
+
+
+def _bias_grad(dy):
+    """Sum over batch and positions of an NC(HW) gradient: our kernel for large planes (tools/bench_channel_sum.py, B = 64:
+    10.7 vs 58 us at 48x56x56, 10.5 vs 16.6 us at 96x28x28), ATen's reduction for small ones (7-8 us vs our 11-12 us)."""
+    hw = dy.numel() // (dy.shape[0] * dy.shape[1])
+    return channel_sum_nchw(dy) if hw >= 512 else dy.sum(dim=tuple(d for d in range(dy.dim()) if d != 1))
+
+
+class ConvBiasFn(torch.autograd.Function):
+    """F.conv2d(x, w, b) (groups = 1) through MIOpen exactly as autograd would run it, except for the bias gradient: ATen's
+    generic reduction takes 59 us for a 64x48x56x56 gradient (0.65 TB/s), mm_channel_sum_nchw a fraction of that."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, stride, padding, dilation):
+        y = torch.nn.functional.conv2d(x, w, b, stride, padding, dilation)
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (list(stride), list(padding), list(dilation), b is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        stride, padding, dilation, has_bias = ctx.cfg
+        dy = dy.contiguous()
+        dx, dw, _ = torch.ops.aten.convolution_backward(dy, x, w, None, stride, padding, dilation, False, [0, 0], 1,
+                                                        [ctx.needs_input_grad[0], ctx.needs_input_grad[1], False])
+        db = _bias_grad(dy) if (has_bias and ctx.needs_input_grad[2]) else None
+        return dx, dw, db, None, None, None
+
+
+def conv2d_bias(x, conv):
+    """nn.Conv2d `conv` applied to x with ConvBiasFn when it is a plain dense conv with a bias on a HIP tensor."""
+    if (x.is_cuda and conv.bias is not None and conv.groups == 1 and conv.padding_mode == "zeros"
+            and not isinstance(conv.padding, str) and x.dtype == torch.float32 and x.is_contiguous()):
+        return ConvBiasFn.apply(x, conv.weight, conv.bias, conv.stride, conv.padding, conv.dilation)
+    return conv(x)
+
+
+class PointwiseConvFn(torch.autograd.Function):
+    """nn.Conv2d(kernel_size=1) on NCHW input as out[b] = W @ x[b] + bias: batched GEMMs with a broadcast weight (MIOpen's
+    weight-gradient kernel for it ran one 64x64 tile per image: 0.39 ms per call at 56x56) and mm_channel_sum_nchw for the
+    bias gradient."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        B, C, H, W = x.shape
+        w = weight.view(weight.shape[0], C)
+        x3 = x.reshape(B, C, H * W)
+        wb = w.unsqueeze(0).expand(B, -1, -1)
+        out = torch.bmm(wb, x3) if bias is None else torch.baddbmm(bias.view(1, -1, 1), wb, x3)
+        ctx.save_for_backward(x3, w)
+        ctx.shape = (B, C, H, W, bias is not None, weight.shape)
+        return out.view(B, -1, H, W)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x3, w = ctx.saved_tensors
+        B, C, H, W, has_bias, wshape = ctx.shape
+        dy3 = dy.contiguous().view(B, -1, H * W)
+        dx = torch.bmm(w.t().unsqueeze(0).expand(B, -1, -1), dy3).view(B, C, H, W) if ctx.needs_input_grad[0] else None
+        dw = torch.bmm(dy3, x3.transpose(1, 2)).sum(0).view(wshape) if ctx.needs_input_grad[1] else None
+        db = _bias_grad(dy3) if (has_bias and ctx.needs_input_grad[2]) else None
+        return dx, dw, db
+
+
 class BlockSplitFn(torch.autograd.Function):
     """SS_Conv_SSM prologue (MedMamba.py:350-352): inp (B,H,W,C) -> (left NCHW (B,C/2,H,W), LayerNorm(right) (B,H,W,C/2),
     inp itself for the residual add of :357).  The backward writes both halves of d(inp) in place — no chunk/cat copies,

@@ -217,3 +217,39 @@ def test_ss2d_conv_core_forward_backward(shape, layout):
     for n, a, b in zip(names, dev_in, ref_in):
         e = (a.grad.cpu() - b.grad).abs().max().item() / max(1.0, b.grad.abs().max().item())
         assert e <= 5e-4, (n, e)
+
+
+@pytest.mark.parametrize("shape", [(64, 48, 56, 56), (3, 5, 7, 9), (2, 300, 4, 4), (1, 8, 1, 1), (5, 16, 10, 6)])
+def test_channel_sum_nchw(shape):
+    from medmamba_amd.ops import channel_sum_nchw
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(*shape, generator=g)
+    ref = x.double().sum(dim=(0, 2, 3))
+    got = channel_sum_nchw(x.to(DEV)).cpu().double()
+    assert (got - ref).abs().max().item() <= 2e-5 * max(1.0, x.abs().sum(dim=(0, 2, 3)).max().item() / 10)
+
+
+def test_conv_bias_and_pointwise_functions_match_autograd():
+    """ConvBiasFn / PointwiseConvFn: same values and gradients as nn.Conv2d under autograd (bias gradient by our kernel)."""
+    from medmamba_amd.ops import PointwiseConvFn, conv2d_bias
+    torch.manual_seed(5)
+    for cin, k, hw in ((24, 3, 14), (48, 3, 9), (16, 3, 32)):        # the last one has planes >= 512 positions: our bias kernel
+        conv = torch.nn.Conv2d(cin, cin, k, padding=k // 2).to(DEV)
+        x = torch.randn(4, cin, hw, hw, device=DEV)
+        gy = torch.randn(4, cin, hw, hw, device=DEV)
+        xa, xb = x.clone().requires_grad_(), x.clone().requires_grad_()
+        ya = conv(xa); ya.backward(gy)
+        ref = [xa.grad.clone(), conv.weight.grad.clone(), conv.bias.grad.clone()]
+        conv.zero_grad(set_to_none=True)
+        yb = conv2d_bias(xb, conv); yb.backward(gy)
+        near = lambda a, b: (a - b).abs().max().item() <= 1e-4 * max(1.0, b.abs().max().item())   # MIOpen may pick another solver
+        assert torch.equal(ya, yb) and near(xb.grad, ref[0]) and near(conv.weight.grad, ref[1]) and near(conv.bias.grad, ref[2])
+    pw = torch.nn.Conv2d(32, 32, 1).to(DEV)
+    x = torch.randn(3, 32, 6, 5, device=DEV); gy = torch.randn(3, 32, 6, 5, device=DEV)
+    xa, xb = x.clone().requires_grad_(), x.clone().requires_grad_()
+    ya = pw(xa); ya.backward(gy)
+    ref = [xa.grad.clone(), pw.weight.grad.clone(), pw.bias.grad.clone()]
+    pw.zero_grad(set_to_none=True)
+    yb = PointwiseConvFn.apply(xb, pw.weight, pw.bias); yb.backward(gy)
+    close = lambda a, b: (a - b).abs().max().item() <= 2e-5 * max(1.0, b.abs().max().item())
+    assert close(yb, ya) and close(xb.grad, ref[0]) and close(pw.weight.grad, ref[1]) and close(pw.bias.grad, ref[2])
