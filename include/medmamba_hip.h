@@ -161,7 +161,7 @@ int mm_plane_transpose(const float* src, int64_t src_sb, int64_t src_sd, float* 
                        int D, int H, int W, void* stream);
 /* out_norm LayerNorm over the D channels (eps) + gate with SiLU(z) (MedMamba.py:300-301), channel-first:
  *   y[b,d,p] = ((m[b,d,p]-mu[b,p])*rstd[b,p]*gamma[d]+beta[d]) * silu(z[b,d,p]);  m,y (batch,D,L); z planes with batch
- *   stride z_sb; mu,rstd (batch,L) outputs.  Backward: dm (batch stride dm_sb), dz (batch stride dz_sb) and per-wave
+ *   stride z_sb; mu,rstd (batch,L) outputs.  Backward: dm, dz and per-workgroup
  *   partial sums ws[row*2*D + (0: dgamma, D: dbeta) + d] for row < mm_ln_gate_rows(batch, D, L) (the caller sums rows). */
 int mm_ln_gate_fwd(const float* m, int64_t m_sb, int64_t m_sd, const float* z, int64_t z_sb, int64_t z_sd, const float* gamma,
                    const float* beta, float eps, float* y, int64_t y_sb, int64_t y_sd, float* mu, float* rstd, int batch, int D,
@@ -176,7 +176,7 @@ int mm_ln_gate_rows(int batch, int D, int L);
  *   left_nchw (batch, C2, P) = inp[..., :C2] transposed (conv-branch input, replaces chunk + permute + contiguous)
  *   rn (batch, P, C2) = LayerNorm_{C2}(inp[..., C2:]) * gamma + beta  (ln_1), statistics mu/rstd (batch*P).
  * Backward writes BOTH halves of dinp (batch, P, 2*C2) — left from dleft_nchw, right from drn, plus dres (batch, P, 2*C2)
- * or NULL: the gradient that reaches the block input through the residual add of MedMamba.py:357 — and per-wave partial
+ * or NULL: the gradient that reaches the block input through the residual add of MedMamba.py:357 — and per-workgroup partial
  * sums ws[row*2*C2 + (0: dgamma, C2: dbeta) + c], row < mm_block_split_rows(batch, P, C2) (the caller sums rows). */
 int mm_block_split_fwd(const float* inp, const float* gamma, const float* beta, float eps, float* left_nchw, float* rn,
                        float* mu, float* rstd, int batch, int P, int C2, void* stream);

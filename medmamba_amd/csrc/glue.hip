@@ -395,7 +395,9 @@ __global__ __launch_bounds__(256) void ln_gate_bwd_kernel(const float* __restric
   c2 = pos_sum<PW>(c2) / D;
   float* dmp = dm + (int64_t)b * dm_sb + p;
   float* dzp = dz + (int64_t)b * dz_sb + p;
-  float* wrow = ws + ((int64_t)blockIdx.x * 4 + wv) * 2 * D;
+  extern __shared__ float sred[];                       // [2*D]: dgamma | dbeta of this workgroup (4 waves add into it)
+  for (int i = threadIdx.x; i < 2 * D; i += blockDim.x) sred[i] = 0.f;
+  __syncthreads();
   for (int d0 = 0; d0 < D; d0 += TPP) {
     const int d = d0 + ck;
     float pg = 0.f, pb_ = 0.f;
@@ -417,10 +419,12 @@ __global__ __launch_bounds__(256) void ln_gate_bwd_kernel(const float* __restric
       pb_ += __shfl_xor(pb_, s);
     }
     if ((lane % PW) == 0 && d < D) {
-      wrow[d] = pg;
-      wrow[D + d] = pb_;
+      atomicAdd(sred + d, pg);
+      atomicAdd(sred + D + d, pb_);
     }
   }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * D; i += blockDim.x) ws[(int64_t)blockIdx.x * 2 * D + i] = sred[i];   // one row per workgroup
 }
 
 inline int pick_pw(int batch, int L) {   // positions per wave: fewer when there are few positions (small images)
@@ -515,7 +519,9 @@ __global__ __launch_bounds__(256) void ln_gate_bwd1_kernel(const float* __restri
   c2 = pos_sum<PW>(c2) / D;
   float* dmp = dm + (int64_t)b * dm_sb + p;
   float* dzp = dz + (int64_t)b * dz_sb + p;
-  float* wrow = ws + ((int64_t)blockIdx.x * 4 + wv) * 2 * D;
+  extern __shared__ float sred[];                       // [2*D]: dgamma | dbeta of this workgroup (4 waves add into it)
+  for (int i = threadIdx.x; i < 2 * D; i += blockDim.x) sred[i] = 0.f;
+  __syncthreads();
 #pragma unroll
   for (int k = 0; k < CPL; ++k) {
     const int d = ck + k * TPP;
@@ -537,10 +543,12 @@ __global__ __launch_bounds__(256) void ln_gate_bwd1_kernel(const float* __restri
       pb_ += __shfl_xor(pb_, s_);
     }
     if ((lane % PW) == 0 && d < D) {
-      wrow[d] = pg;
-      wrow[D + d] = pb_;
+      atomicAdd(sred + d, pg);
+      atomicAdd(sred + D + d, pb_);
     }
   }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * D; i += blockDim.x) ws[(int64_t)blockIdx.x * 2 * D + i] = sred[i];   // one row per workgroup
 }
 
 // plan of the LayerNorm + gate kernels: positions per wave and, for the single-pass kernels, channels per lane
@@ -588,7 +596,7 @@ int launch_ln_bwd1(int cpl, dim3 grid, hipStream_t s, const float* dy, int64_t d
                    int64_t m_sd, const float* z, int64_t z_sb, int64_t z_sd, const float* gamma, const float* beta, const float* mu,
                    const float* rstd, float* dm, int64_t dm_sb, int64_t dm_sd, float* dz, int64_t dz_sb, int64_t dz_sd, float* ws,
                    int D, int L, int npb) {
-#define MM_LN_BWD1(CPL_) hipLaunchKernelGGL((ln_gate_bwd1_kernel<PW, CPL_>), grid, dim3(256), 0, s, dy, dy_sb, dy_sd, m, m_sb, m_sd, \
+#define MM_LN_BWD1(CPL_) hipLaunchKernelGGL((ln_gate_bwd1_kernel<PW, CPL_>), grid, dim3(256), 2 * D * sizeof(float), s, dy, dy_sb, dy_sd, m, m_sb, m_sd, \
                                             z, z_sb, z_sd, gamma, beta, mu, rstd, dm, dm_sb, dm_sd, dz, dz_sb, dz_sd, ws, D, L, npb)
   switch (cpl) {
     case 8: MM_LN_BWD1(8); break;
@@ -649,7 +657,7 @@ int mm_plane_transpose(const float* src, int64_t src_sb, int64_t src_sd, float* 
 
 int mm_ln_gate_rows(int batch, int D, int L) {   // rows of the dgamma/dbeta workspace written by mm_ln_gate_bwd
   const int pw = plan_ln(batch, D, L, true).pw;
-  return batch * ((L + 4 * pw - 1) / (4 * pw)) * 4;
+  return batch * ((L + 4 * pw - 1) / (4 * pw));
 }
 
 int mm_ln_gate_fwd(const float* m, int64_t m_sb, int64_t m_sd, const float* z, int64_t z_sb, int64_t z_sd, const float* gamma,
@@ -685,9 +693,9 @@ int mm_ln_gate_bwd(const float* dy, int64_t dy_sb, int64_t dy_sd, const float* m
     return pw == 16 ? launch_ln_bwd1<16>(pl.cpl, grid, s, dy, dy_sb, dy_sd, m, m_sb, m_sd, z, z_sb, z_sd, gamma, beta, mu, rstd, dm, dm_sb, dm_sd, dz, dz_sb, dz_sd, ws, D, L, npb)
                     : launch_ln_bwd1<4>(pl.cpl, grid, s, dy, dy_sb, dy_sd, m, m_sb, m_sd, z, z_sb, z_sd, gamma, beta, mu, rstd, dm, dm_sb, dm_sd, dz, dz_sb, dz_sd, ws, D, L, npb);
   }
-  if (pw == 64) hipLaunchKernelGGL(ln_gate_bwd_kernel<64>, grid, blk, 0, s, dy, dy_sb, dy_sd, m, m_sb, m_sd, z, z_sb, z_sd, gamma, beta, mu, rstd, dm, dm_sb, dm_sd, dz, dz_sb, dz_sd, ws, D, L, npb);
-  else if (pw == 16) hipLaunchKernelGGL(ln_gate_bwd_kernel<16>, grid, blk, 0, s, dy, dy_sb, dy_sd, m, m_sb, m_sd, z, z_sb, z_sd, gamma, beta, mu, rstd, dm, dm_sb, dm_sd, dz, dz_sb, dz_sd, ws, D, L, npb);
-  else hipLaunchKernelGGL(ln_gate_bwd_kernel<4>, grid, blk, 0, s, dy, dy_sb, dy_sd, m, m_sb, m_sd, z, z_sb, z_sd, gamma, beta, mu, rstd, dm, dm_sb, dm_sd, dz, dz_sb, dz_sd, ws, D, L, npb);
+  if (pw == 64) hipLaunchKernelGGL(ln_gate_bwd_kernel<64>, grid, blk, 2 * D * sizeof(float), s, dy, dy_sb, dy_sd, m, m_sb, m_sd, z, z_sb, z_sd, gamma, beta, mu, rstd, dm, dm_sb, dm_sd, dz, dz_sb, dz_sd, ws, D, L, npb);
+  else if (pw == 16) hipLaunchKernelGGL(ln_gate_bwd_kernel<16>, grid, blk, 2 * D * sizeof(float), s, dy, dy_sb, dy_sd, m, m_sb, m_sd, z, z_sb, z_sd, gamma, beta, mu, rstd, dm, dm_sb, dm_sd, dz, dz_sb, dz_sd, ws, D, L, npb);
+  else hipLaunchKernelGGL(ln_gate_bwd_kernel<4>, grid, blk, 2 * D * sizeof(float), s, dy, dy_sb, dy_sd, m, m_sb, m_sd, z, z_sb, z_sd, gamma, beta, mu, rstd, dm, dm_sb, dm_sd, dz, dz_sb, dz_sd, ws, D, L, npb);
   return (int)hipGetLastError();
 }
 
@@ -798,8 +806,10 @@ __global__ __launch_bounds__(256) void ln_half_bwd_kernel(const float* __restric
       }
     }
   }
-  // fold the RPW row slots of the wave (lanes with equal lr), then one partial row per wave
-  float* wrow = ws + wave_global * 2 * C2;
+  // fold the RPW row slots of the wave (lanes with equal lr), then the 4 waves through LDS: one partial row per workgroup
+  extern __shared__ float sred[];                       // [2*C2]
+  for (int i = threadIdx.x; i < 2 * C2; i += blockDim.x) sred[i] = 0.f;
+  __syncthreads();
 #pragma unroll
   for (int k = 0; k < kLnNV; ++k) {
     float a = ag[k], bsum = ab[k];
@@ -808,8 +818,10 @@ __global__ __launch_bounds__(256) void ln_half_bwd_kernel(const float* __restric
       bsum += __shfl_xor(bsum, 16); bsum += __shfl_xor(bsum, 32);
     }
     const int c = lr + k * TPR;
-    if (lane < TPR && c < C2) { wrow[c] = a; wrow[C2 + c] = bsum; }
+    if (lane < TPR && c < C2) { atomicAdd(sred + c, a); atomicAdd(sred + C2 + c, bsum); }
   }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C2; i += blockDim.x) ws[(int64_t)blockIdx.x * 2 * C2 + i] = sred[i];
 }
 
 // dst[b, i, p] = src[b, p, i] for i < C2 (src row stride C): NHWC half -> NCHW.  REV: the other way round
@@ -857,7 +869,7 @@ __global__ __launch_bounds__(256) void half_transpose_kernel(const float* __rest
 inline int ln_half_grid(int64_t nrows, int tpr) {
   const int64_t waves = (nrows + (64 / tpr) - 1) / (64 / tpr);
   int64_t blocks = (waves + 3) / 4;
-  if (blocks > 2048) blocks = 2048;
+  if (blocks > 1024) blocks = 1024;       // >= 16 waves per CU; every workgroup leaves ONE partial dgamma/dbeta row
   return (int)blocks;
 }
 }  // namespace
@@ -865,7 +877,7 @@ inline int ln_half_grid(int64_t nrows, int tpr) {
 extern "C" {
 
 int mm_block_split_rows(int batch, int P, int C2) {   // rows of the dgamma/dbeta workspace of mm_block_split_bwd
-  return ln_half_grid((int64_t)batch * P, C2 <= 128 ? 16 : 64) * 4;
+  return ln_half_grid((int64_t)batch * P, C2 <= 128 ? 16 : 64);
 }
 
 int mm_block_split_fwd(const float* inp, const float* gamma, const float* beta, float eps, float* left_nchw, float* rn,
@@ -891,8 +903,8 @@ int mm_block_split_bwd(const float* dleft_nchw, const float* drn, const float* d
   const int C = 2 * C2;
   const int64_t nrows = (int64_t)batch * P;
   hipLaunchKernelGGL(half_transpose_kernel<true>, dim3(((P + 31) / 32) * ((C2 + 31) / 32) * batch), dim3(256), 0, s, dleft_nchw, dinp, dres, P, C, C2);
-  if (C2 <= 128) hipLaunchKernelGGL(ln_half_bwd_kernel<16>, dim3(ln_half_grid(nrows, 16)), dim3(256), 0, s, drn, inp, gamma, mu, rstd, dres, dinp, ws, nrows, C, C2);
-  else hipLaunchKernelGGL(ln_half_bwd_kernel<64>, dim3(ln_half_grid(nrows, 64)), dim3(256), 0, s, drn, inp, gamma, mu, rstd, dres, dinp, ws, nrows, C, C2);
+  if (C2 <= 128) hipLaunchKernelGGL(ln_half_bwd_kernel<16>, dim3(ln_half_grid(nrows, 16)), dim3(256), 2 * C2 * sizeof(float), s, drn, inp, gamma, mu, rstd, dres, dinp, ws, nrows, C, C2);
+  else hipLaunchKernelGGL(ln_half_bwd_kernel<64>, dim3(ln_half_grid(nrows, 64)), dim3(256), 2 * C2 * sizeof(float), s, drn, inp, gamma, mu, rstd, dres, dinp, ws, nrows, C, C2);
   return (int)hipGetLastError();
 }
 
