@@ -563,7 +563,8 @@ inline LnPlan plan_ln(int batch, int D, int L, bool bwd) {
   // measured (tools/bench_ln_gate.py, B = 64): forward 86 -> 48 / 39 -> 36 / 40 -> 31 / 38 -> 27 us for the four S stages;
   // backward only wins where 16 lanes share a position and still own <= 24 channels (D = 384: 80 -> 55 us) — with 4
   // lanes per position it writes 4x the partial-sum rows (165 -> 158 us at D = 96, 60 -> 70 us at D = 192)
-  const bool fits = bwd ? (tpp == 16 && need > 16 && need <= 24) : need <= 48;
+  static const int bwd_all = [] { const char* e = getenv("MM_LN_BWD1_ALL"); return e ? atoi(e) : 0; }();
+  const bool fits = bwd ? ((bwd_all ? true : (tpp == 16 && need > 16)) && need <= 24) : need <= 48;
   if (fits && !(two_pass & (bwd ? 2 : 1))) {
     pl.pw = 64 / tpp;
     pl.cpl = need <= 8 ? 8 : need <= 16 ? 16 : need <= 24 ? 24 : need <= 32 ? 32 : 48;
