@@ -221,6 +221,9 @@ __global__ __launch_bounds__(512) void scan_bwd_kernel(const BwdParams p) {
     float* accb = acc_lane + buf * 2 * kNState * TS;
     for (int sub = nsub - 1; sub >= 0; --sub) {
       const int ts = sub * kChunk;
+      // 4-step groups of this sub-tile that hold real time steps (the last sub-tile of a sequence whose length is not a
+      // multiple of 16 is partly padding: L = 196 -> 4 of 16 steps, L = 49 -> 1 of 16); the others are skipped entirely
+      const int ntq = (min(kChunk, p.L - (t0 + ts)) + 3) >> 2;
       float xs[kChunk][NS];
       const float x0[NS] = {x0n.x, x0n.y, x0n.z, x0n.w};
       {   // prefetch the checkpoint of the NEXT sub-tile to be processed
@@ -233,6 +236,7 @@ __global__ __launch_bounds__(512) void scan_bwd_kernel(const BwdParams p) {
       // forward recompute of the 16 states
 #pragma unroll
       for (int tq = 0; tq < 4; ++tq) {
+        if (tq >= ntq) continue;
         const int to = ts + 4 * tq;
         const float4 dl4 = *reinterpret_cast<const float4*>(s_dl + c * TS + to);
         const float4 u4 = *reinterpret_cast<const float4*>(s_u + c * TS + to);
@@ -253,6 +257,7 @@ __global__ __launch_bounds__(512) void scan_bwd_kernel(const BwdParams p) {
       // adjoint recurrence, backwards
 #pragma unroll
       for (int tq = 3; tq >= 0; --tq) {
+        if (tq >= ntq) continue;
         const int to = ts + 4 * tq;
         const float4 dl4 = *reinterpret_cast<const float4*>(s_dl + c * TS + to);
         const float4 u4 = *reinterpret_cast<const float4*>(s_u + c * TS + to);
