@@ -10,7 +10,8 @@ dev = torch.device("cuda:0")
 torch.manual_seed(42)
 net = VSSM(num_classes=6, **MEDMAMBA_CONFIGS["S"]).to(dev).train()
 opt = torch.optim.AdamW(net.parameters(), lr=1e-4, weight_decay=1e-4, fused=True)
-x = torch.randn(64, 3, 224, 224, device=dev); y = torch.randint(0, 6, (64,), device=dev)
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+x = torch.randn(B, 3, 224, 224, device=dev); y = torch.randint(0, 6, (B,), device=dev)
 def step():
     opt.zero_grad(set_to_none=True)
     loss = torch.nn.functional.cross_entropy(net(x), y); loss.backward(); opt.step()
