@@ -379,8 +379,10 @@ class SS_Conv_SSM(nn.Module):
             left = conv_body(left)                                                           # stays NCHW
         # trailing ReLU + drop_path + permute back + cat + channel_shuffle(groups=2) + residual (MedMamba.py:347, 353-357)
         # fused in one HIP kernel
-        return shuffle_residual(left, x_cf, input, channel_first=True, ssm_scale=self.drop_path.factor(x_cf),
-                                left_relu=fold_relu)
+        scale = getattr(self, "_dp_factor", None)      # drawn for all blocks at once by VSSM.forward_backbone
+        if scale is None:
+            scale = self.drop_path.factor(x_cf)
+        return shuffle_residual(left, x_cf, input, channel_first=True, ssm_scale=scale, left_relu=fold_relu)
 
 
 class VSSLayer(nn.Module):
@@ -457,10 +459,32 @@ class VSSM(nn.Module):
     def no_weight_decay_keywords(self):
         return {'relative_position_bias_table'}
 
+    def _draw_drop_path(self, batch, device):
+        """All blocks' DropPath factors (mask / keep_prob, MedMamba.py:335) of this step in two launches instead of two per
+        block; the blocks pick theirs up in SS_Conv_SSM.forward.  Only on HIP tensors in training mode and without
+        activation checkpointing (a recomputed block must see the mask of its first run)."""
+        blocks = [b for layer in self.layers if not layer.use_checkpoint for b in layer.blocks
+                  if isinstance(b.drop_path, DropPath) and b.drop_path.drop_prob > 0.0 and b.drop_path.scale_by_keep]
+        if not blocks:
+            return []
+        key = (batch, str(device), tuple(b.drop_path.drop_prob for b in blocks))
+        if getattr(self, "_dp_key", None) != key:
+            keep = torch.tensor([1.0 - b.drop_path.drop_prob for b in blocks], device=device, dtype=torch.float32)
+            self._dp_key, self._dp_keep = key, keep[:, None].expand(-1, batch).contiguous()
+        factors = torch.bernoulli(self._dp_keep).div_(self._dp_keep)
+        for i, b in enumerate(blocks):
+            b._dp_factor = factors[i]
+        return blocks
+
     def forward_backbone(self, x):
-        x = self.pos_drop(self.patch_embed(x))
-        for layer in self.layers:
-            x = layer(x)
+        drawn = self._draw_drop_path(x.shape[0], x.device) if (self.training and x.is_cuda) else []
+        try:
+            x = self.pos_drop(self.patch_embed(x))
+            for layer in self.layers:
+                x = layer(x)
+        finally:
+            for b in drawn:
+                b._dp_factor = None
         return x
 
     def forward(self, x):

@@ -214,3 +214,34 @@ def test_odd_and_non_square_images_same_in_both_layouts(monkeypatch, capsys):
             scale = max(1e-4, g0[k].abs().max().item())
             assert (g1[k] - g0[k]).abs().max().item() <= 2e-3 * scale, (layout, two, k)
     capsys.readouterr()         # the crop warning of PatchMerging2D
+
+
+def test_drop_path_factors_are_drawn_once_per_step(monkeypatch):
+    """Training mode: VSSM draws every block's DropPath factor (mask / keep_prob, MedMamba.py:335, 353) in one go; the blocks
+    consume them through shuffle_residual and none falls back to its own draw."""
+    from medmamba_amd import modules
+    torch.manual_seed(2)
+    net = modules.VSSM(num_classes=3, depths=[1, 1, 2, 1], dims=[16, 32, 64, 128], drop_path_rate=0.5).to(DEV).train()
+    x = torch.randn(16, 3, 32, 32, device=DEV)
+    seen = {}
+    orig = modules.shuffle_residual
+
+    def spy(left, ssm, inp, channel_first=False, ssm_scale=None, left_relu=False):
+        seen[len(seen)] = None if ssm_scale is None else ssm_scale.detach().clone()
+        return orig(left, ssm, inp, channel_first=channel_first, ssm_scale=ssm_scale, left_relu=left_relu)
+
+    monkeypatch.setattr(modules, "shuffle_residual", spy)
+    def no_own_draw(self, x):
+        assert self.drop_prob == 0.0, "per-block draw"
+        return None
+
+    monkeypatch.setattr(modules.DropPath, "factor", no_own_draw)
+    net(x).sum().backward()
+    probs = [b.drop_path.drop_prob for layer in net.layers for b in layer.blocks]
+    assert len(seen) == 5 and seen[0] is None and probs[0] == 0.0          # first block: drop_prob 0 -> no factor
+    for i in range(1, 5):
+        keep = 1.0 - probs[i]
+        f = seen[i].cpu()
+        assert f.shape == (16,) and bool(((f == 0) | ((f - 1.0 / keep).abs() < 1e-6)).all())
+    assert all(getattr(b, "_dp_factor", None) is None for layer in net.layers for b in layer.blocks)
+    assert any(bool((seen[i] == 0).any()) for i in range(1, 5)) and any(bool((seen[i] != 0).any()) for i in range(1, 5))
