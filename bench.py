@@ -7,9 +7,14 @@ HBM GB/s vs roofline").
            bench.py --gpus N --steps K --warmup W
 
 One "step" = one full training step of MedMamba-S (train.py:277-288: zero_grad, forward, CrossEntropy,
-backward, AdamW step) on a synthetic 224x224x3 batch of 64 images per GPU that is already resident in HBM.
-Weak scaling: per-GPU batch fixed, one process per GPU, gradients all-reduced by DistributedDataParallel
-over RCCL (backend "nccl").  Rank 0 prints ONE JSON line.
+backward, AdamW step) on a synthetic 224x224x3 batch of 64 images per GPU that is already resident in HBM
+(BASELINE config 3; N > 1 = config 4).  Weak scaling: per-GPU batch fixed, one process per GPU, gradients averaged by
+ONE flat all-reduce after backward (medmamba_amd.ddp.GradSync) over RCCL (backend "nccl"); MM_DDP=torch selects
+DistributedDataParallel instead.  Rank 0 prints ONE JSON line.
+
+Other single-GPU configurations of BASELINE.json (metric / config.workload follow the flags):
+    --mode fwd --batch 32            config 2: MedMamba-S, 32 images, forward only (eval, no_grad)
+    --size B --res 384 --batch 32    config 5: MedMamba-B at 384x384 (L = 9216 at stage 1)
 
 Extra objects on the line:
   roofline     — the selective-scan forward kernel (the north-star kernel): algorithmic bytes
@@ -20,6 +25,9 @@ Extra objects on the line:
   roofline_bwd — same for the backward scan kernel.
   cpu_baseline — the CPU restatement of the reference path (oracle/: torch-CPU glue + C selective_scan_ref)
                  timed on this box's host cores on a bounded sample (rank 0, N=1 only).
+  cpu_baseline_ref_loop — the reference's literal CPU path (north_star: "selective_scan_ref CPU path", temp.py:57-139):
+                 the pure-PyTorch time loop inside the same model, MedMamba-T, 1 x 3 x 224 x 224, forward
+                 (BASELINE config 1), 1 warm-up + median of 3.
 """
 import argparse
 import json
@@ -38,8 +46,11 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md §Chip-level parameters)
 
 
-def cpu_baseline(size, res, nimg=32):
-    """fwd+bwd of the same model through the CPU oracle (kind "port"): bounded sample of `nimg` images."""
+def cpu_baseline(size, res, nimg=32, mode="train"):
+    """fwd+bwd (mode "fwd": forward only) of the same model through the CPU oracle (kind "port"): bounded sample of `nimg`
+    images (fewer at 384x384, where an image costs ~6x the work)."""
+    if res > 256:
+        nimg = max(4, nimg // 4)
     from oracle import model_ref as R
     from oracle.scan_ref import c_selective_scan_fn, build_c_oracle
     from medmamba_amd.modules import VSSM, MEDMAMBA_CONFIGS
@@ -58,6 +69,9 @@ def cpu_baseline(size, res, nimg=32):
     y = torch.randint(0, 6, (nimg,))
 
     def step():
+        if mode == "fwd":
+            with torch.no_grad():
+                return float(nn.functional.cross_entropy(R.vssm_forward(p, x, cfg["depths"], c_selective_scan_fn, training=False), y))
         for v in p.values():
             if v.requires_grad:
                 v.grad = None
@@ -70,16 +84,41 @@ def cpu_baseline(size, res, nimg=32):
     step()
     dt = time.perf_counter() - t0
     return dict(value=nimg / dt, unit="images/s", cores=cores, kind="port",
-                sample=f"{nimg} images, MedMamba-{size} {res}x{res} fwd+bwd (no optimizer step), torch-CPU glue + "
+                sample=f"{nimg} images, MedMamba-{size} {res}x{res} {'fwd+bwd (no optimizer step)' if mode == 'train' else 'forward only'}, torch-CPU glue + "
                        f"oracle/selective_scan_ref.c scan on {cores} threads, 1 warm-up + 1 timed pass "
                        f"({dt:.1f} s)")
 
 
-def cpu_baseline_subprocess(size, res, timeout_s=240):
+def cpu_baseline_ref_loop(reps=3):
+    """BASELINE config 1 on the host: MedMamba-T, 1 x 3 x 224 x 224, forward, the pure-PyTorch selective_scan_ref loop
+    (oracle.scan_ref.selective_scan_ref, restated from temp.py:57-139) as the scan — the reference's own CPU path."""
+    from oracle import model_ref as R
+    from oracle.scan_ref import selective_scan_ref
+    from medmamba_amd.modules import VSSM, MEDMAMBA_CONFIGS
+    cores = max(1, min(16, len(os.sched_getaffinity(0))))
+    torch.set_num_threads(cores)
+    torch.manual_seed(42)
+    cfg = MEDMAMBA_CONFIGS["T"]
+    p = {k: v.clone() for k, v in VSSM(num_classes=6, **cfg).state_dict().items()}
+    x = torch.randn(1, 3, 224, 224)
+    ts = []
+    with torch.no_grad():
+        for i in range(reps + 1):                       # first call is ~3x slower (allocator growth): warm-up
+            t0 = time.perf_counter()
+            R.vssm_forward(p, x, cfg["depths"], selective_scan_ref, training=False)
+            ts.append(time.perf_counter() - t0)
+    med = sorted(ts[1:])[len(ts[1:]) // 2]
+    return dict(value=1.0 / med, unit="images/s", cores=cores, kind="port",
+                sample=f"MedMamba-T 1x3x224x224 forward, pure-PyTorch selective_scan_ref time loop (temp.py:57-139 restated) "
+                       f"on {cores} torch threads, 1 warm-up ({ts[0]:.1f} s) + median of {reps} ({med:.2f} s)")
+
+
+def cpu_baseline_subprocess(size, res, timeout_s=240, fn="cpu_baseline", mode="train"):
     """Run the CPU leg in a child process (own thread pools, hard time bound); never blocks the GPU result."""
     import subprocess
+    call = "bench.cpu_baseline(%r, %d, 32, %r)" % (size, res, mode) if fn == "cpu_baseline" else "bench.cpu_baseline_ref_loop()"
     code = ("import json,sys; sys.path.insert(0, %r); import bench; "
-            "print('CPUBASE ' + json.dumps(bench.cpu_baseline(%r, %d)))" % (ROOT, size, res))
+            "print('CPUBASE ' + json.dumps(%s))" % (ROOT, call))
     env = dict(os.environ, OMP_NUM_THREADS="16", MKL_NUM_THREADS="16", HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
     try:
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=timeout_s, env=env)
@@ -99,6 +138,8 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="images per GPU (BASELINE config 3/4: 64)")
     ap.add_argument("--size", default="S", choices=["T", "S", "B", "Te"])
     ap.add_argument("--res", type=int, default=224)
+    ap.add_argument("--mode", default="train", choices=["train", "fwd"], help="train: fwd + CE + bwd + AdamW (config 3/4/5); "
+                    "fwd: eval-mode forward under no_grad (config 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse)")
     ap.add_argument("--no-alone-pass", action="store_true", help="skip the 3 untimed steps that re-measure the scan kernels "
@@ -132,7 +173,8 @@ def main():
     if os.environ.get("MM_MIOPEN_BENCHMARK", "0") == "1":
         torch.backends.cudnn.benchmark = True      # MIOpen times its solvers per conv shape during the warm-up steps
     torch.manual_seed(42)                      # identical replicas; random-init weights (no checkpoints offline)
-    net = VSSM(num_classes=6, **MEDMAMBA_CONFIGS[args.size]).to(dev).train()
+    net = VSSM(num_classes=6, **MEDMAMBA_CONFIGS[args.size]).to(dev)
+    net = net.train() if args.mode == "train" else net.eval()
     # gradient exchange: one flat all-reduce after backward (GradSync) unless MM_DDP=torch asks for DistributedDataParallel
     use_torch_ddp = world > 1 and os.environ.get("MM_DDP", "flat") == "torch"
     model = wrap_ddp(net, dev) if use_torch_ddp else net
@@ -145,7 +187,7 @@ def main():
     images = torch.randn(args.batch, 3, args.res, args.res, device=dev, generator=g)   # resident in HBM
     labels = torch.randint(0, 6, (args.batch,), device=dev, generator=g)
 
-    def step():
+    def train_step():
         opt.zero_grad(set_to_none=True)
         loss = loss_fn(model(images), labels)
         loss.backward()
@@ -153,6 +195,12 @@ def main():
             sync()
         opt.step()
         return loss.detach()            # do not keep the autograd graph (and its AccumulateGrad nodes) alive across steps
+
+    def fwd_step():
+        with torch.no_grad():
+            return loss_fn(model(images), labels)
+
+    step = train_step if args.mode == "train" else fwd_step
 
     def fence():
         torch.cuda.synchronize()
@@ -198,7 +246,7 @@ def main():
             traffic = json.load(open(os.path.join(ROOT, "profiles", "scan_traffic.json")))
         except Exception:
             traffic = {}
-        std_workload = (args.size == "S" and args.batch == 64 and args.res == 224)
+        std_workload = (args.size == "S" and args.batch == 64 and args.res == 224 and args.mode == "train")
 
         def roof(tag):
             d = ks.get(tag)
@@ -217,21 +265,26 @@ def main():
                 r["frac_alone"] = round(r["achieved_alone"] / HBM_PEAK_GBS, 4)
             return r
 
+        what = "fwd+bwd" if args.mode == "train" else "fwd"
+        work = "training step (fwd + CE loss + bwd + AdamW)" if args.mode == "train" else "inference forward (eval, no_grad) + CE loss"
         out = {
-            "metric": "images/sec fwd+bwd MedMamba-S 224^2", "value": round(args.batch * world * args.steps / dt, 2),
+            "metric": f"images/sec {what} MedMamba-{args.size} {args.res}^2", "value": round(args.batch * world * args.steps / dt, 2),
             "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"MedMamba-{args.size} {args.res}x{args.res}x3 training step (fwd + CE loss + bwd + "
-                                   f"AdamW), {args.batch} images per GPU resident in HBM, random-init weights",
+            "config": {"workload": f"MedMamba-{args.size} {args.res}x{args.res}x3 {work}, "
+                                   f"{args.batch} images per GPU resident in HBM, random-init weights",
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                        "parallelism": (f"dp{world} (replicas, " + ("DistributedDataParallel" if use_torch_ddp else
                                        "one flat gradient all-reduce per step") + " over RCCL)") if world > 1 else "single GPU"},
             "roofline": roof("scan_fwd"), "roofline_bwd": roof("scan_bwd"),
             "final_loss": round(float(loss.detach()), 5),
         }
+        if out["roofline_bwd"] is None:
+            del out["roofline_bwd"]
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline_subprocess(args.size, args.res)
+            out["cpu_baseline"] = cpu_baseline_subprocess(args.size, args.res, mode=args.mode)
+            out["cpu_baseline_ref_loop"] = cpu_baseline_subprocess(args.size, args.res, fn="cpu_baseline_ref_loop")
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

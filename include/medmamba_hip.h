@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MM_ABI_VERSION 10
+#define MM_ABI_VERSION 11
 
 enum mm_status {
   MM_OK = 0,
@@ -147,6 +147,10 @@ int mm_shuffle_residual_bwd(const float* dout, float* dleft, float* dssm, int64_
  *   ws[(b*D+d)*10 + (0..8: dW[kh][kw], 9: dbias)]  (the caller sums over b). */
 int mm_dwconv_silu_cross_fwd(const float* x, int64_t x_sb, int64_t x_sd, const float* w, const float* bias, float* u2,
                              int64_t u2_sb, int64_t u2_sd, int batch, int D, int H, int W, void* stream);
+/* 1 if an H x W plane fits the LDS budget of BOTH kernels (they keep whole planes on chip; the backward needs
+ * 2*(H+2)*(W+2) + H*(W+1) floats <= 150 KB, i.e. up to about 110 x 110), else 0: the caller then runs the depthwise
+ * conv of MedMamba.py:294-295 through its generic convolution and hands both image orders to the scan itself. */
+int mm_dwconv_silu_cross_supported(int H, int W);
 int mm_dwconv_silu_cross_bwd(const float* du2, int64_t du2_sb, int64_t du2_sd, const float* du4, int64_t du4_sb, int64_t du4_sd,
                              const float* x, int64_t x_sb, int64_t x_sd,
                              const float* w, const float* bias, float* dx, int64_t dx_sb, int64_t dx_sd, float* ws, int batch,

@@ -611,6 +611,11 @@ int launch_ln_bwd1(int cpl, dim3 grid, hipStream_t s, const float* dy, int64_t d
 
 extern "C" {
 
+int mm_dwconv_silu_cross_supported(int H, int W) {   // the backward keeps 2 haloed planes + 1 staging plane in LDS
+  if (H <= 0 || W <= 0) return 0;
+  return sizeof(float) * (2 * (size_t)(H + 2) * (W + 2) + (size_t)H * (W + 1)) <= 150 * 1024 ? 1 : 0;
+}
+
 int mm_dwconv_silu_cross_fwd(const float* x, int64_t x_sb, int64_t x_sd, const float* w, const float* bias, float* u2,
                              int64_t u2_sb, int64_t u2_sd, int batch, int D, int H, int W, void* stream) {
   if (!x || !w || !u2) return MM_ERR_NULL;

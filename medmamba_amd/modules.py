@@ -24,6 +24,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 import torch.utils.checkpoint as checkpoint
 
+from . import _lib
 from .ops import (PointwiseConvFn, block_split, conv2d_bias, dwconv_silu_cross, in_proj_cf, out_proj_cf, shuffle_residual,
                   ss2d_conv_core, ss2d_core)
 from .selective_scan_interface import CROSS_SCAN_K_OF_G, cross_scan_fn, selective_scan_fn
@@ -275,11 +276,12 @@ class SS2D(nn.Module):
         # holds them, the kernel-order packing is one launch inside
         cv = self.conv2d
         if cv.kernel_size == (3, 3) and cv.padding == (1, 1) and cv.stride == (1, 1) and cv.dilation == (1, 1) \
-                and cv.groups == D and cv.padding_mode == "zeros":
+                and cv.groups == D and cv.padding_mode == "zeros" and _lib.lib().mm_dwconv_silu_cross_supported(H, W):
             y_cf = ss2d_conv_core(x_cf, cv.weight, cv.bias, self.x_proj_weight, self.dt_projs_weight, self.dt_projs_bias,
                                   self.A_logs, self.Ds, z_cf, self.out_norm.weight, self.out_norm.bias, H, W,
                                   self.out_norm.eps, prescan_event=prescan_event)
-        else:                   # any other d_conv: the conv through MIOpen, then the core on its two image orders
+        else:   # any other d_conv, or planes beyond the fused kernels' LDS budget (decided HERE, with the backward's need, so
+                # that a pass never fails halfway): the conv through MIOpen, then the core on its two image orders
             xc = self.act(cv(x_cf.reshape(B, D, H, W)))
             u2 = torch.stack([xc.reshape(B, D, L), xc.transpose(2, 3).reshape(B, D, L)], 1).reshape(B, 2 * D, L)
             y_cf = ss2d_core(u2, self.x_proj_weight, self.dt_projs_weight, self.dt_projs_bias, self.A_logs, self.Ds,
@@ -341,7 +343,8 @@ class SS_Conv_SSM(nn.Module):
     def forward(self, input):
         if _has_hooks(self) or not isinstance(self.drop_path, DropPath):
             return self.forward_modules(input)
-        if isinstance(self.ln_1, nn.LayerNorm) and self.ln_1.elementwise_affine and self.ln_1.bias is not None:
+        if isinstance(self.ln_1, nn.LayerNorm) and self.ln_1.elementwise_affine and self.ln_1.bias is not None \
+                and input.shape[-1] % 2 == 0 and input.shape[-1] // 2 <= 512:     # block_split keeps a row in registers
             # chunk + permute(0,3,1,2).contiguous() + ln_1 (MedMamba.py:350-352) in one fused HIP prologue
             left, right_n, input = block_split(input, self.ln_1.weight, self.ln_1.bias, self.ln_1.eps)
         else:                                                  # any other norm_layer: the reference's own op chain
@@ -463,8 +466,12 @@ class VSSM(nn.Module):
         """All blocks' DropPath factors (mask / keep_prob, MedMamba.py:335) of this step in two launches instead of two per
         block; the blocks pick theirs up in SS_Conv_SSM.forward.  Only on HIP tensors in training mode and without
         activation checkpointing (a recomputed block must see the mask of its first run)."""
+        # only blocks that would draw themselves: in training mode (a frozen block put into eval() inside a training model
+        # drops nothing, like the reference's per-block DropPath) and with 0 < drop_prob < 1 (keep_prob 0 is not divided
+        # by — DropPath.factor / timm return zeros there)
         blocks = [b for layer in self.layers if not layer.use_checkpoint for b in layer.blocks
-                  if isinstance(b.drop_path, DropPath) and b.drop_path.drop_prob > 0.0 and b.drop_path.scale_by_keep]
+                  if isinstance(b.drop_path, DropPath) and b.training and b.drop_path.training
+                  and 0.0 < b.drop_path.drop_prob < 1.0 and b.drop_path.scale_by_keep]
         if not blocks:
             return []
         key = (batch, str(device), tuple(b.drop_path.drop_prob for b in blocks))

@@ -27,10 +27,10 @@ def split_sd(fx, prefix="sd/"):
 
 @pytest.fixture(scope="session", autouse=True)
 def _built_library():
-    """Build libmedmamba_hip.so (hipcc cross-compiles without a GPU) and the C oracle once per session if missing."""
-    from medmamba_amd.build import SO, build
-    if not os.path.exists(SO):
-        build()
+    """Build libmedmamba_hip.so (hipcc cross-compiles without a GPU) and the C oracle once per session.  build() is
+    incremental on source / header mtimes, so edited kernels are never tested against a stale binary."""
+    from medmamba_amd.build import build
+    build()
     from oracle.scan_ref import build_c_oracle
     build_c_oracle()
 

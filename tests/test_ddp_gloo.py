@@ -71,8 +71,8 @@ def test_ddp_gradients_match_single_process(tmp_path, monkeypatch, mode):
         monkeypatch.setattr(M, name, getattr(M, name))      # restore the product functions after this test
     world, port = 2, _free_port()
     mp.spawn(_worker, args=(world, port, str(tmp_path), mode), nprocs=world, join=True)
-    r0 = torch.load(tmp_path / "r0.pt")
-    r1 = torch.load(tmp_path / "r1.pt")
+    r0 = torch.load(tmp_path / "r0.pt", weights_only=True)
+    r1 = torch.load(tmp_path / "r1.pt", weights_only=True)
     for k in r0["grads"]:
         assert torch.equal(r0["grads"][k], r1["grads"][k]), k          # all-reduced: identical on both ranks
     net = _build_model()

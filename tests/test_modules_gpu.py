@@ -77,9 +77,10 @@ def test_tiny_vssm_logits_loss_and_grads():
     assert worst <= 5e-3, worst      # fp32 training-mode grads through 4 blocks incl. BatchNorm batch statistics
 
 
-@pytest.mark.parametrize("size", ["T", "S"])
+@pytest.mark.parametrize("size", ["T", "S", "B"])
 def test_seed_kat_full_model_logits(size):
-    """BASELINE config 1: seed 42 -> same init -> logits of the reference (CPU, restated scan) at 224x224."""
+    """BASELINE config 1 (T, S at 224x224) and the config-5 model (B at 384x384: 96x96 planes, D up to 1024, R up to 32):
+    seed 42 -> same init -> logits of the reference (CPU, restated scan)."""
     from medmamba_amd.modules import VSSM
     kat = json.load(open(os.path.join(GOLDEN, "kat_seed42.json")))[size]
     torch.manual_seed(42)
@@ -245,3 +246,113 @@ def test_drop_path_factors_are_drawn_once_per_step(monkeypatch):
         assert f.shape == (16,) and bool(((f == 0) | ((f - 1.0 / keep).abs() < 1e-6)).all())
     assert all(getattr(b, "_dp_factor", None) is None for layer in net.layers for b in layer.blocks)
     assert any(bool((seen[i] == 0).any()) for i in range(1, 5)) and any(bool((seen[i] != 0).any()) for i in range(1, 5))
+
+
+def test_config2_S_batch32_inference_vs_oracle_slice():
+    """BASELINE config 2: MedMamba-S, 32 x 3 x 224 x 224, forward only (no_grad, eval: the x_chk = NULL / need_grad = False
+    kernels).  eval-mode BatchNorm makes images independent, so two images of the batch are checked against the CPU oracle
+    model (oracle.model_ref.vssm_forward with the C scan) run on just those two."""
+    from medmamba_amd.modules import VSSM, MEDMAMBA_CONFIGS
+    from oracle import model_ref as R
+    from oracle.scan_ref import c_selective_scan_fn
+    torch.manual_seed(42)
+    cfg = MEDMAMBA_CONFIGS["S"]
+    net = VSSM(num_classes=6, **cfg).eval()
+    x = torch.randn(32, 3, 224, 224)
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    with torch.no_grad():
+        got = net.to(DEV)(x.to(DEV)).cpu()
+        pick = [5, 31]
+        want = R.vssm_forward(sd, x[pick], cfg["depths"], c_selective_scan_fn, training=False)
+    assert got.shape == (32, 6) and torch.isfinite(got).all()
+    _close(got[pick], want.numpy(), 1e-3, "logits of images 5 and 31")
+    # batch independence in eval mode: the same two images alone give the same logits
+    with torch.no_grad():
+        alone = net(x[pick].to(DEV)).cpu()
+    _close(alone, got[pick].numpy(), 2e-4, "batch of 2 vs slice of the batch of 32")
+
+
+def test_activation_checkpointing_with_drop_path_matches_plain_run(monkeypatch):
+    """use_checkpoint=True (MedMamba.py:414-415) in training mode with DropPath: the recomputed blocks must see the mask of
+    their first run and the side-stream schedule must survive the recompute inside backward -> same loss and gradients as
+    the plain run with the same RNG state."""
+    from medmamba_amd import modules
+    monkeypatch.setattr(modules.VSSM, "_draw_drop_path", lambda self, batch, device: [])    # per-block draws in both runs
+    x = torch.randn(6, 3, 64, 64, device=DEV)
+    y = torch.randint(0, 3, (6,), device=DEV)
+    res = {}
+    for ck in (False, True):
+        torch.manual_seed(5)
+        net = modules.VSSM(num_classes=3, depths=[1, 2, 1, 1], dims=[16, 32, 64, 128], drop_path_rate=0.4,
+                           use_checkpoint=ck).to(DEV).train()
+        torch.manual_seed(77)
+        torch.cuda.manual_seed(77)
+        loss = torch.nn.functional.cross_entropy(net(x), y)
+        loss.backward()
+        res[ck] = (float(loss), {k: p.grad.clone() for k, p in net.named_parameters()})
+    assert abs(res[True][0] - res[False][0]) <= 1e-6 * abs(res[False][0])
+    for k, g0 in res[False][1].items():
+        scale = max(1e-4, float(g0.abs().max()))
+        assert float((res[True][1][k] - g0).abs().max()) <= 2e-3 * scale, k
+
+
+def test_frozen_block_and_full_drop_rate(monkeypatch):
+    """a block put into eval() inside a training model drops nothing (no pre-drawn factor reaches it), and
+    drop_prob = 1.0 yields zeros, not NaN."""
+    from medmamba_amd import modules
+    torch.manual_seed(2)
+    net = modules.VSSM(num_classes=3, depths=[1, 1, 2, 1], dims=[16, 32, 64, 128], drop_path_rate=0.5).to(DEV).train()
+    frozen = net.layers[2].blocks[1]
+    frozen.eval()
+    net.layers[3].blocks[0].drop_path.drop_prob = 1.0
+    seen = []
+    orig = modules.shuffle_residual
+
+    def spy(left, ssm, inp, channel_first=False, ssm_scale=None, left_relu=False):
+        seen.append(None if ssm_scale is None else ssm_scale.detach().clone())
+        return orig(left, ssm, inp, channel_first=channel_first, ssm_scale=ssm_scale, left_relu=left_relu)
+
+    monkeypatch.setattr(modules, "shuffle_residual", spy)
+    out = net(torch.randn(8, 3, 32, 32, device=DEV))
+    assert torch.isfinite(out).all()
+    assert len(seen) == 5
+    assert seen[3] is None                                   # the frozen block: no DropPath factor at all
+    assert seen[4] is not None and bool((seen[4] == 0).all()) and bool(torch.isfinite(seen[4]).all())
+
+
+def test_planes_beyond_the_fused_kernels_lds_budget():
+    """ADVICE r1 / VERDICT weak #9: a 120 x 120 feature map exceeds the LDS budget of the fused depthwise-conv kernels;
+    SS2D.forward_cf decides at forward time and routes to the generic conv + ss2d_core — forward and backward run and agree
+    with the module-by-module path (HIP scan operator)."""
+    from medmamba_amd import _lib
+    from medmamba_amd.modules import SS2D
+    assert _lib.lib().mm_dwconv_silu_cross_supported(56, 56) == 1
+    assert _lib.lib().mm_dwconv_silu_cross_supported(120, 120) == 0
+    torch.manual_seed(4)
+    m = SS2D(d_model=2).to(DEV)
+    x = torch.randn(1, 120, 120, 2, device=DEV, requires_grad=True)
+    y = m(x)
+    y.square().mean().backward()
+    g = x.grad.clone(); x.grad = None
+    gp = {k: p.grad.clone() for k, p in m.named_parameters()}
+    m.zero_grad()
+    y2 = m.forward_modules(x)
+    y2.square().mean().backward()
+    _close(y, y2.detach().cpu().numpy(), 1e-4, "y")
+    _close(g, x.grad.cpu().numpy(), 1e-3, "dx")
+    for k, p in m.named_parameters():
+        w = p.grad.cpu().numpy()
+        assert np.abs(gp[k].cpu().numpy() - w).max() <= 2e-3 * max(1e-4, np.abs(w).max()), k
+
+
+def test_wide_block_beyond_block_split_limit():
+    """hidden_dim = 2048 (C/2 = 1024 > 512): the block prologue falls back to the reference op chain instead of raising."""
+    from medmamba_amd.modules import SS_Conv_SSM
+    torch.manual_seed(6)
+    blk = SS_Conv_SSM(hidden_dim=2048, drop_path=0.0, norm_layer=torch.nn.LayerNorm).to(DEV).train()
+    x = torch.randn(1, 3, 4, 2048, device=DEV, requires_grad=True)
+    y = blk(x)
+    y.mean().backward()
+    y2 = blk.forward_modules(x.detach())
+    _close(y, y2.detach().cpu().numpy(), 2e-4, "y")
+    assert torch.isfinite(x.grad).all()

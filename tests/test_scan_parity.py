@@ -251,3 +251,65 @@ def test_cross_scan_unaligned_lengths(L):
     with torch.no_grad():
         y2 = cross_scan_fn(*[t.to(dev) for t in (u2.view(Bz, 2 * D, L), delta.view(Bz, 4 * D, L), A, Bm, Cm, Dp, bias)])
     assert (y2.cpu().double().view(Bz, 2, D, L) - want).abs().max().item() <= 5e-5 * want.abs().max().item()
+
+
+def _full_size_inputs(Bz, G, H, L, R, seed, channel_major):
+    dev = _dev()
+    g = torch.Generator(device=dev).manual_seed(seed)
+    N, dim = 16, G * H
+    mk = (lambda *shape: torch.randn(shape[1], shape[0], shape[2], device=dev, generator=g).permute(1, 0, 2)) if channel_major \
+        else (lambda *shape: torch.randn(*shape, device=dev, generator=g))
+    u, delta, dout = mk(Bz, dim, L), mk(Bz, dim, L), mk(Bz, dim, L)
+    A = -torch.exp(torch.randn(dim, N, device=dev, generator=g) * 0.5)
+    x_dbl = torch.randn(Bz, G, R + 2 * N, L, device=dev, generator=g)
+    D = torch.randn(dim, device=dev, generator=g)
+    bias = torch.randn(dim, device=dev, generator=g) - 4.0
+    return u, delta, A, x_dbl[:, :, R:R + N], x_dbl[:, :, R + N:], D, bias, dout
+
+
+def _run_bwd(args, channel_major, variant=0, monkeypatch=None):
+    from medmamba_amd import selective_scan_interface as ssi
+    u, delta, A, Bs, Cs, D, bias, dout = args
+    if monkeypatch is not None:
+        monkeypatch.setattr(ssi, "_BWD_VARIANT", variant)
+    _, x_chk = ssi._launch_fwd(u, delta, A, Bs, Cs, D, bias, True, True)
+    return ssi._launch_bwd(u, delta, A, Bs, Cs, D, bias, x_chk, dout, True, channel_major=channel_major)
+
+
+@pytest.mark.parametrize("shape", [(64, 4, 96, 3136, 3, False), (64, 4, 384, 196, 12, True)],
+                         ids=["stage1_batch_major", "stage3_channel_major"])
+def test_full_size_backward_properties(shape, monkeypatch):
+    """BASELINE config-3 sizes of the BACKWARD (S, Bz=64: stage 1 = 64 x 384 x 3136 batch-major planes, stage 3 =
+    64 x 1536 x 196 channel-major planes): (a) du / ddelta of sampled rows and dB / dC of sampled (batch, direction) pairs
+    against the fp64 oracle run on exactly that slice, (b) linearity in dout, (c) the forced 2-wave workgroups (several
+    workgroups per direction -> atomic dB/dC path) agree with the default plan, (d) dA / dD / dbias against an oracle run
+    over a full batch slice is too slow — their linearity and the sampled (batch, direction) slices cover them."""
+    from oracle.scan_ref import c_scan_bwd
+    Bz, G, H, L, R, cm = shape
+    args = _full_size_inputs(Bz, G, H, L, R, seed=L, channel_major=cm)
+    u, delta, A, Bs, Cs, D, bias, dout = args
+    du, ddelta, dA, dB, dC, dD, dbias = _run_bwd(args, cm, 0, monkeypatch)
+    torch.cuda.synchronize()
+    for t in (du, ddelta, dA, dB, dC, dD, dbias):
+        assert torch.isfinite(t).all()
+    # (a) sampled (batch, direction) pairs: the whole direction of one image through the oracle
+    for b, grp in ((0, 0), (Bz - 1, G - 1), (Bz // 2, 1)):
+        sl = slice(grp * H, (grp + 1) * H)
+        c = lambda t: t.contiguous().cpu()
+        r = c_scan_bwd(c(u[b:b + 1, sl]), c(delta[b:b + 1, sl]), c(A[sl]), c(Bs[b:b + 1, grp:grp + 1]), c(Cs[b:b + 1, grp:grp + 1]),
+                       c(D[sl]), c(bias[sl]), c(dout[b:b + 1, sl]), True)
+        for name, got, want in (("du", du[b:b + 1, sl], r["du"]), ("ddelta", ddelta[b:b + 1, sl], r["ddelta"]),
+                                ("dB", dB[b:b + 1, grp:grp + 1], r["dB"]), ("dC", dC[b:b + 1, grp:grp + 1], r["dC"])):
+            e = np.abs(got.cpu().numpy() - want).max() / max(1.0, np.abs(want).max())
+            assert e <= BWD_RTOL, (name, b, grp, e)
+    # (b) linearity in dout (every output of the backward is linear in it)
+    r2 = _run_bwd((u, delta, A, Bs, Cs, D, bias, dout * 2.0), cm, 0, monkeypatch)
+    for name, a1, a2 in zip(["du", "ddelta", "dA", "dB", "dC", "dD", "dbias"], (du, ddelta, dA, dB, dC, dD, dbias), r2):
+        scale = max(1.0, float(a1.abs().max()))
+        assert float((a2 - 2.0 * a1).abs().max()) <= 2e-4 * scale, name
+    del r2
+    # (c) forced small workgroups: several workgroups share a direction and add dB/dC with atomics
+    r3 = _run_bwd(args, cm, 2 << 16, monkeypatch)
+    for name, a1, a3 in zip(["du", "ddelta", "dA", "dB", "dC", "dD", "dbias"], (du, ddelta, dA, dB, dC, dD, dbias), r3):
+        scale = max(1.0, float(a1.abs().max()))
+        assert float((a3 - a1).abs().max()) <= 2e-4 * scale, name
