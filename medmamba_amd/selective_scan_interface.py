@@ -52,6 +52,7 @@ class _KernelTimer:
 
 KERNEL_TIMER = _KernelTimer()
 _BWD_VARIANT = int(__import__("os").environ.get("MM_BWD_VARIANT", "0"))   # tuning knob: waves per workgroup << 16
+_FWD_VARIANT = int(__import__("os").environ.get("MM_FWD_VARIANT", "0"))   # tuning knob: forward kernel / states per lane when a call passes 0
 
 
 def scan_bytes_fwd(batch, dim, L, N, G):
@@ -120,7 +121,7 @@ def _launch_fwd(u, delta, A, B, C, D, delta_bias, delta_softplus, want_chk, vari
         x_chk = torch.empty((batch, dim, (L + chunk - 1) // chunk, A.shape[1]), device=u.device, dtype=torch.float32)
     a = _lib.ScanArgs()
     _fill_common(a, u, delta, A, B, C, D, delta_bias, delta_softplus)
-    a.out, a.x_chk, a.variant = out.data_ptr(), _ptr(x_chk), int(variant)
+    a.out, a.x_chk, a.variant = out.data_ptr(), _ptr(x_chk), int(variant) or _FWD_VARIANT
     a.u_groups, a.u_map, a.rev_mask = shared
     with _lib.device_guard(u.device):
         t0 = KERNEL_TIMER.start()
