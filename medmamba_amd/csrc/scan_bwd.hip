@@ -11,8 +11,9 @@
 //     b = dlu*B;  gxt = C*g + gx;  w = x - b (= a*x_prev);  t2 = gxt*w;  dA += t2*dl;  s1 += t2*A;  s2 += gxt*B;
 //     dC_part = g*x;  dB_part = gxt*dlu;  gx = a*gxt              [ddelta' = s1 + u*s2,  du = dl*s2 + D*g]
 // dB/dC: an 8-value halving butterfly inside each 16-lane row (22 DPP ops per step instead of 32) leaves one sum
-// per lane, one ds_add_f32 per step accumulates the workgroup's waves in LDS; the accumulators are double
-// buffered and flushed one tile later, so the whole tile loop has ONE barrier per tile.
+// per lane, which goes to the wave's own LDS slab with a plain store (LDS float atomics are slow: ~40 ns of the CU's
+// LDS pipe per ds_add_f32 with 32 active lanes, tools/ubench/lds_rate.cpp); the slabs are double buffered and
+// summed over the waves + flushed one tile later, so the whole tile loop has ONE barrier per tile.
 // Global traffic uses bounds-checked buffer descriptors (mm_common.h) and a register prefetch of the next
 // tile; reversed directions / shared u blocks as in the forward kernel (include/medmamba_hip.h).
 #include "mm_common.h"
@@ -73,9 +74,10 @@ __global__ __launch_bounds__(512) void scan_bwd_kernel(const BwdParams p) {
   const int ugrp = p.ug < p.G ? (int)((p.u_map >> (4 * grp)) & 15) : grp;
   const bool rev = grp < 32 && ((p.rev_mask >> grp) & 1);
 
+  const int nwaves = nthreads >> 6;
   float* sBC = smem;                                   // [2 buf][2][16][TS]   B, C tiles
-  float* sAcc = smem + 2 * 2 * kNState * TS;           // [2 buf][2][16][TS]   dB, dC accumulators
-  float* wl = smem + 4 * 2 * kNState * TS + wave * (3 * CH * TS);
+  float* sAcc = smem + 2 * 2 * kNState * TS;           // [2 buf][nwaves][2][16][TS]   dB, dC partial sums, one slab per wave
+  float* wl = smem + (2 + 2 * nwaves) * 2 * kNState * TS + wave * (3 * CH * TS);
   float* s_u = wl;                                     // u      -> du   (in place)
   float* s_dl = wl + CH * TS;                          // delta' -> ddelta' (in place)
   float* s_g = wl + 2 * CH * TS;                       // dout
@@ -98,7 +100,7 @@ __global__ __launch_bounds__(512) void scan_bwd_kernel(const BwdParams p) {
   // which of the 8 reduced dB/dC sums this lane ends up with (butterfly below): idx = 4*bit2 + 2*bit3 + bit0
   // (the lanes with bit1 set hold duplicates and stay out of the LDS atomic)
   const int ridx = ((c >> 2) & 1) * 4 + ((c >> 3) & 1) * 2 + (c & 1);
-  float* acc_lane = sAcc + ((ridx >> 2) * kNState + g * NS + (ridx & 3)) * TS;   // + buf*2*16*TS + t
+  float* acc_lane = sAcc + ((wave * 2 + (ridx >> 2)) * kNState + g * NS + (ridx & 3)) * TS;   // + buf*nwaves*2*16*TS + t
 
   // ---- staging identity: lane -> (row r of an 8-row group, float4 column q)
   const int r = lane / QL, q = lane % QL;
@@ -147,13 +149,19 @@ __global__ __launch_bounds__(512) void scan_bwd_kernel(const BwdParams p) {
     if (nthreads >= 256) pbc = load_quad<VEC>(bc_which ? rC : rB, bc_off, t0 + 4 * bc_q, p.L, rev, bc_mine);
   };
 
-  // flush one accumulator buffer (tile starting at t0) to global and clear it
+  // flush one buffer of per-wave partial sums (tile starting at t0) to global: sum over the workgroup's waves.
+  // (Plain stores into per-wave slabs + this sum replace LDS float atomics: ds_add_f32 costs ~40 ns of the CU's LDS
+  //  pipe per wave-instruction with 32 active lanes — tools/ubench/lds_rate.cpp — i.e. 8 waves x 1 per step = 320 ns of
+  //  every ~540 ns step at the 56x56 stage.)
   auto flush_acc = [&](int buf, int t0) {
     for (int idx = tid; idx < 256; idx += nthreads) {
       const int which = idx >> 7, n = (idx >> 3) & 15, qq = idx & 7;
-      float* a = sAcc + ((buf * 2 + which) * kNState + n) * TS + 4 * qq;
-      const float4 v = *reinterpret_cast<const float4*>(a);
-      *reinterpret_cast<float4*>(a) = make_float4(0.f, 0.f, 0.f, 0.f);
+      const float* a = sAcc + ((buf * nwaves * 2 + which) * kNState + n) * TS + 4 * qq;
+      float4 v = *reinterpret_cast<const float4*>(a);
+      for (int w = 1; w < nwaves; ++w) {
+        const float4 o = *reinterpret_cast<const float4*>(a + w * 2 * kNState * TS);
+        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+      }
       float* dst = which ? dCbase + n * p.dC_sn : dBbase + n * p.dB_sn;
       const int t = t0 + 4 * qq;
 #pragma unroll
@@ -167,7 +175,8 @@ __global__ __launch_bounds__(512) void scan_bwd_kernel(const BwdParams p) {
     }
   };
 
-  for (int idx = tid; idx < 2 * 2 * kNState * TS; idx += nthreads) sAcc[idx] = 0.f;
+  // (no zero-fill of the slabs: every cell that a flush reads for a time step < L was written by its wave in that tile;
+  //  cells of skipped padding groups are never flushed)
 
   issue_loads((p.ntiles - 1) * T);
   // checkpoint prefetch for the first sub-tile to be processed (the state BEFORE sub-tile `sub` of `tile`)
@@ -218,7 +227,7 @@ __global__ __launch_bounds__(512) void scan_bwd_kernel(const BwdParams p) {
     const int nsub = (tlen + kChunk - 1) / kChunk;
     const float* sB = sBC + ((buf * 2 + 0) * kNState + g * NS) * TS;
     const float* sC = sBC + ((buf * 2 + 1) * kNState + g * NS) * TS;
-    float* accb = acc_lane + buf * 2 * kNState * TS;
+    float* accb = acc_lane + buf * nwaves * 2 * kNState * TS;
     for (int sub = nsub - 1; sub >= 0; --sub) {
       const int ts = sub * kChunk;
       // 4-step groups of this sub-tile that hold real time steps (the last sub-tile of a sequence whose length is not a
@@ -331,7 +340,7 @@ __global__ __launch_bounds__(512) void scan_bwd_kernel(const BwdParams p) {
             const bool b0 = c & 1;
             float w1 = dpp_add<DPP_QUAD_XOR1>(b0 ? v[1] : v[0], b0 ? v[0] : v[1]);   // pair i <-> i^1; bit0 decides
             w1 += dpp_f<DPP_QUAD_XOR2>(w1);           // pair i <-> i^2 (both lanes end with the full sum)
-            if (!(c & 2)) atomicAdd(accb + to + e, w1);
+            if (!(c & 2)) accb[to + e] = w1;       // this wave's own slab: a plain ds_write_b32
           }
         }
         if (g == 0) *reinterpret_cast<float4*>(s_dl + c * TS + to) = ddl4;
@@ -378,7 +387,7 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 template <bool VEC, bool SP>
 int launch(const BwdParams& p, int nblocks, int waves, hipStream_t stream) {
-  const size_t lds = sizeof(float) * (4 * 2 * kNState * TS + (size_t)waves * 3 * CH * TS);
+  const size_t lds = sizeof(float) * ((2 + 2 * (size_t)waves) * 2 * kNState * TS + (size_t)waves * 3 * CH * TS);
   if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)scan_bwd_kernel<VEC, SP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL((scan_bwd_kernel<VEC, SP>), dim3(nblocks), dim3(waves * 64), lds, stream, p);
   return (int)hipGetLastError();

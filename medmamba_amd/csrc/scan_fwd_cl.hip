@@ -406,7 +406,7 @@ int scan_fwd_cl_launch(const mm_scan_args* a, int ns, hipStream_t stream) {
   p.ug = shared ? a->u_groups : a->G;
   p.u_map = shared ? a->u_map : 0x76543210u;
   p.rev_mask = a->rev_mask;
-  if (ns != 4 && ns != 8 && ns != 16) return MM_ERR_UNSUPPORTED;
+  if (ns != 4 && ns != 8) return MM_ERR_UNSUPPORTED;   // (the single-wave NS = 16 form fails the reversed-direction parity test: not offered)
   p.ctiles = (p.H + 63) / 64;
   const int64_t sdmax = a->u_sd > a->delta_sd ? a->u_sd : a->delta_sd;
   const int64_t span = 64 * (sdmax > a->L ? sdmax : a->L) * 4;       // one workgroup touches <= 64 rows
@@ -417,11 +417,7 @@ int scan_fwd_cl_launch(const mm_scan_args* a, int ns, hipStream_t stream) {
   const bool vec = (a->L % 4 == 0) && aligned16(a->u) && aligned16(a->delta) && aligned16(a->out) && a->u_sb % 4 == 0 &&
                    a->u_sd % 4 == 0 && a->delta_sb % 4 == 0 && a->delta_sd % 4 == 0;
   const bool sp = a->delta_softplus != 0;
-  switch (ns) {
-    case 4: return launch_cl_ns<4>(p, nblocks, vec, sp, stream);
-    case 8: return launch_cl_ns<8>(p, nblocks, vec, sp, stream);
-    default: return launch_cl_ns<16>(p, nblocks, vec, sp, stream);
-  }
+  return ns == 4 ? launch_cl_ns<4>(p, nblocks, vec, sp, stream) : launch_cl_ns<8>(p, nblocks, vec, sp, stream);
 }
 
 }  // namespace mm

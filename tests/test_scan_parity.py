@@ -114,7 +114,7 @@ def test_golden_forward_and_backward(name):
         assert e <= 3e-4, (k, e)
 
 
-@pytest.mark.parametrize("variant", [1, 2, 4, 20, 24, 32])      # 16 + NS: the channel-lane kernel (scan_fwd_cl.hip)
+@pytest.mark.parametrize("variant", [1, 2, 4, 20, 24])      # 16 + NS: the channel-lane kernel (scan_fwd_cl.hip)
 @pytest.mark.parametrize("shape", [(2, 4, 8, 37), (1, 4, 24, 196), (2, 4, 96, 64), (1, 2, 5, 130), (3, 4, 32, 49),
                                    (1, 4, 16, 257), (1, 1, 16, 1)])
 def test_forward_vs_oracle(shape, variant):
@@ -315,7 +315,7 @@ def test_full_size_backward_properties(shape, monkeypatch):
         assert float((a3 - a1).abs().max()) <= 2e-4 * scale, name
 
 
-@pytest.mark.parametrize("variant", [20, 24, 32])
+@pytest.mark.parametrize("variant", [20, 24])
 def test_channel_lane_forward_kernel(variant, monkeypatch):
     """scan_fwd_cl.hip (lane = channel, B/C as SGPR operands, states split over the wavefronts of a workgroup): real stage
     shapes incl. a 96-channel direction (one full + one half-filled 64-channel tile), options, checkpoints consumed by
