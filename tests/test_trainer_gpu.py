@@ -1,0 +1,43 @@
+"""GPU: the flag-compatible trainer end to end on synthetic batches — checkpoint files as the reference names them, and a
+resumed run continues like the uninterrupted one (reference flow: train.py:208-260, 271-362)."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(tmp, name, epochs, resume=None):
+    import train
+    save = os.path.join(tmp, name)
+    argv = ["--synthetic", "--steps", "3", "--val_steps", "1", "--epochs", str(epochs), "--medmb_size", "T", "--res", "64",
+            "--batch_size", "4", "--num_classes", "5", "--drop_path_rate", "0", "--save_dir", save, "--seed", "7"]
+    if resume:
+        argv += ["--resume", resume]
+    assert train.main(argv) == 0
+    return save
+
+
+def test_synthetic_training_checkpoints_and_resume(tmp_path):
+    tmp = str(tmp_path)
+    a = _run(tmp, "a", 2)                                           # two epochs in one go
+    b1 = _run(tmp, "b", 1)                                          # one epoch ...
+    last1 = os.path.join(b1, "Medmamba_epoch_1_last.pth")
+    assert os.path.isfile(last1) and os.path.isfile(os.path.join(b1, "class_indices.json"))
+    _run(tmp, "b", 2, resume=last1)                                 # ... resumed for the second
+    ca = torch.load(os.path.join(a, "Medmamba_epoch_2_last.pth"), weights_only=True)
+    cb = torch.load(os.path.join(b1, "Medmamba_epoch_2_last.pth"), weights_only=True)
+    assert set(ca) == {"epoch", "model_state_dict", "optimizer_state_dict", "best_acc", "num_classes", "class_indices"}
+    assert ca["epoch"] == cb["epoch"] == 2 and ca["num_classes"] == 5
+    # same weights up to the run-to-run noise of the fp32 atomics in the backward scan (1e-7 per step)
+    for k, va in ca["model_state_dict"].items():
+        vb = cb["model_state_dict"][k]
+        if va.dtype.is_floating_point:
+            assert float((va - vb).abs().max()) <= 1e-4 * max(1e-2, float(va.abs().max())), k
+        else:
+            assert torch.equal(va, vb), k                            # BatchNorm step counters
+    sa, sb = ca["optimizer_state_dict"]["state"], cb["optimizer_state_dict"]["state"]
+    assert len(sa) == len(sb) and all(float(sa[i]["step"]) == float(sb[i]["step"]) == 6.0 for i in sa)
+    bests = [f for f in os.listdir(a) if f.endswith("_best.pth")]
+    assert len(bests) <= 1                                           # only the newest best checkpoint is kept (train.py:333-337)
