@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MM_ABI_VERSION 11
+#define MM_ABI_VERSION 13
 
 enum mm_status {
   MM_OK = 0,
@@ -179,14 +179,32 @@ int mm_ln_gate_rows(int batch, int D, int L);
 /* Block prologue of SS_Conv_SSM.forward (MedMamba.py:350-352): inp (batch, P, 2*C2) NHWC ->
  *   left_nchw (batch, C2, P) = inp[..., :C2] transposed (conv-branch input, replaces chunk + permute + contiguous)
  *   rn (batch, P, C2) = LayerNorm_{C2}(inp[..., C2:]) * gamma + beta  (ln_1), statistics mu/rstd (batch*P).
+ * left_affine (optional, inference): [scale C2 | shift C2] applied to the left half while it is transposed — the eval-mode
+ *   BatchNorm2d that opens the conv branch (MedMamba.py:338), folded: left_nchw[b,i,p] = inp[b,p,i]*scale[i] + shift[i]
+ *   (before the convolution's zero padding, so exact at the image border).  NULL = plain copy; the backward assumes NULL.
  * Backward writes BOTH halves of dinp (batch, P, 2*C2) — left from dleft_nchw, right from drn, plus dres (batch, P, 2*C2)
  * or NULL: the gradient that reaches the block input through the residual add of MedMamba.py:357 — and per-workgroup partial
  * sums ws[row*2*C2 + (0: dgamma, C2: dbeta) + c], row < mm_block_split_rows(batch, P, C2) (the caller sums rows). */
-int mm_block_split_fwd(const float* inp, const float* gamma, const float* beta, float eps, float* left_nchw, float* rn,
-                       float* mu, float* rstd, int batch, int P, int C2, void* stream);
+int mm_block_split_fwd(const float* inp, const float* gamma, const float* beta, float eps, const float* left_affine,
+                       float* left_nchw, float* rn, float* mu, float* rstd, int batch, int P, int C2, void* stream);
 int mm_block_split_bwd(const float* dleft_nchw, const float* drn, const float* dres, const float* inp, const float* gamma,
                        const float* mu, const float* rstd, float* dinp, float* ws, int batch, int P, int C2, void* stream);
 int mm_block_split_rows(int batch, int P, int C2);
+
+/* PatchMerging2D front half (MedMamba.py:93-116): 2x2 strided gather (reference channel order x0..x3 = (even row, even col),
+ * (odd, even), (even, odd), (odd, odd); odd H / W cropped to the even part, :97-111) + LayerNorm over the 4*C gathered channels,
+ * one pass:  x (batch, H, W, C) NHWC -> out (batch, H/2, W/2, 4*C) = LN(gather(x)) * gamma + beta, statistics mu / rstd
+ * (batch * H/2 * W/2).  The Linear(4C -> 2C) of :117 stays a GEMM on `out`.
+ * Backward: dy (same shape as out) -> dinp (batch, H, W, C) at the gathered positions (the caller zero-fills dinp when H or W
+ * is odd: the cropped row / column receives no gradient) and per-wavefront partial sums
+ * ws[row * 8*C + (0: dgamma | 4*C: dbeta) + c], row < mm_patch_merge_ln_rows(batch, H, W) (the caller sums the rows).
+ * mm_patch_merge_ln_supported(C): C % 4 == 0 and 4*C <= 2048 (a row lives in one wavefront's registers); 16-B aligned pointers. */
+int mm_patch_merge_ln_supported(int C);
+int mm_patch_merge_ln_rows(int batch, int H, int W);
+int mm_patch_merge_ln_fwd(const float* x, const float* gamma, const float* beta, float eps, float* out, float* mu, float* rstd,
+                          int batch, int H, int W, int C, void* stream);
+int mm_patch_merge_ln_bwd(const float* dy, const float* x, const float* gamma, const float* mu, const float* rstd, float* dinp,
+                          float* ws, int batch, int H, int W, int C, void* stream);
 
 /* SS2D parameters (MedMamba.py:150-175) -> one buffer in kernel direction order, A = -exp(A_logs) (MedMamba.py:271):
  *   x_proj_w (4, C, D), dt_w (4, D, R), dt_b (4, D), A_logs (4*D, N), Ds (4*D) in the reference's direction order

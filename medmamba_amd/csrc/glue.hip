@@ -852,7 +852,9 @@ __global__ __launch_bounds__(256) void half_transpose_kernel(const float* __rest
 #pragma unroll
     for (int r = ty; r < 32; r += 8) {           // rows i, lanes along p
       const int i = i0 + r, p = p0 + tx;
-      if (i < C2 && p < P) d[(int64_t)i * P + p] = tile[tx][r];
+      // `add` doubles as the optional per-channel affine [scale C2 | shift C2] of the forward direction (eval-mode
+      // BatchNorm in front of the conv branch folded into this copy: applied BEFORE the conv's zero padding, hence exact)
+      if (i < C2 && p < P) d[(int64_t)i * P + p] = add ? fmaf(tile[tx][r], add[i], add[C2 + i]) : tile[tx][r];
     }
   } else {
     const float* s = src + (int64_t)b * C2 * P;
@@ -886,15 +888,15 @@ int mm_block_split_rows(int batch, int P, int C2) {   // rows of the dgamma/dbet
   return ln_half_grid((int64_t)batch * P, C2 <= 128 ? 16 : 64);
 }
 
-int mm_block_split_fwd(const float* inp, const float* gamma, const float* beta, float eps, float* left_nchw, float* rn,
-                       float* mu, float* rstd, int batch, int P, int C2, void* stream) {
+int mm_block_split_fwd(const float* inp, const float* gamma, const float* beta, float eps, const float* left_affine,
+                       float* left_nchw, float* rn, float* mu, float* rstd, int batch, int P, int C2, void* stream) {
   if (!inp || !gamma || !beta || !left_nchw || !rn || !mu || !rstd) return MM_ERR_NULL;
   if (batch <= 0 || P <= 0 || C2 <= 0) return MM_ERR_SHAPE;
   if (C2 > 8 * 64) return MM_ERR_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   const int C = 2 * C2;
   const int64_t nrows = (int64_t)batch * P;
-  hipLaunchKernelGGL(half_transpose_kernel<false>, dim3(((P + 31) / 32) * ((C2 + 31) / 32) * batch), dim3(256), 0, s, inp, left_nchw, nullptr, P, C, C2);
+  hipLaunchKernelGGL(half_transpose_kernel<false>, dim3(((P + 31) / 32) * ((C2 + 31) / 32) * batch), dim3(256), 0, s, inp, left_nchw, left_affine, P, C, C2);
   if (C2 <= 128) hipLaunchKernelGGL(ln_half_fwd_kernel<16>, dim3(ln_half_grid(nrows, 16)), dim3(256), 0, s, inp, gamma, beta, eps, rn, mu, rstd, nrows, C, C2);
   else hipLaunchKernelGGL(ln_half_fwd_kernel<64>, dim3(ln_half_grid(nrows, 64)), dim3(256), 0, s, inp, gamma, beta, eps, rn, mu, rstd, nrows, C, C2);
   return (int)hipGetLastError();

@@ -1,0 +1,178 @@
+// PatchMerging2D (MedMamba.py:79-119) front half in one pass over HBM: the 2x2 strided gather with the reference's
+// channel order (x0 = even row / even col, x1 = odd row / even col, x2 = even row / odd col, x3 = odd / odd; odd H or W are
+// cropped to the even part, MedMamba.py:97-111) + LayerNorm over the 4C gathered channels.  The Linear(4C -> 2C) that
+// follows stays a library GEMM on the rows this kernel writes.
+//
+// One wavefront per output position; a row of 4C floats = C float4, lane l holds float4 l, l+64, ... (<= 8 of them:
+// 4C <= 2048) in registers between the statistics and the output pass, so every operand crosses HBM once (ATen's
+// LayerNorm on a materialised gather reads / writes the 4C-wide rows three times and ran below 0.4 TB/s on them).
+// Exact two-pass statistics (mean, then centred sum of squares) like torch.nn.LayerNorm.
+// Backward: d(x) is written straight into the gathered positions of d(input) (the cropped last row / column of an odd
+// image is zero-filled by the caller), dgamma / dbeta leave as one partial row per wavefront (the caller sums them).
+#include "mm_common.h"
+#include "medmamba_hip.h"
+
+namespace {
+using namespace mm;
+
+__device__ __forceinline__ float wave_sum(float v) {
+  v = group_sum<16>(v);
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 32);
+  return v;
+}
+
+struct PmGeom { int H, W, C, h2, w2, C4; };   // C4 = C / 4 float4 per source pixel
+
+// source float4 index (inside the NHWC input) of float4 j of output row `row`
+__device__ __forceinline__ int64_t pm_src(const PmGeom& g, int64_t row, int j) {
+  const int s = j / g.C4, o = j - s * g.C4;
+  const int w2i = (int)(row % g.w2);
+  const int64_t t = row / g.w2;
+  const int h2i = (int)(t % g.h2);
+  const int64_t b = t / g.h2;
+  const int hh = 2 * h2i + (s & 1), ww = 2 * w2i + (s >> 1);
+  return ((b * g.H + hh) * g.W + ww) * (int64_t)g.C4 + o;
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void patch_merge_ln_fwd_kernel(const float4* __restrict__ x, const float4* __restrict__ gamma,
+                                                                 const float4* __restrict__ beta, float eps, float4* __restrict__ out,
+                                                                 float* __restrict__ mu_out, float* __restrict__ rstd_out,
+                                                                 int64_t nrows, PmGeom g) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave_global = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+  const float inv_n = 1.f / (4 * g.C);
+  for (int64_t row = wave_global; row < nrows; row += nwaves) {
+    float4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int j = lane + 64 * k;
+      v[k] = j < g.C ? x[pm_src(g, row, j)] : make_float4(0.f, 0.f, 0.f, 0.f);
+      s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+    }
+    const float mean = wave_sum(s) * inv_n;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      if (lane + 64 * k < g.C) {
+        const float a = v[k].x - mean, b = v[k].y - mean, c = v[k].z - mean, d = v[k].w - mean;
+        q += (a * a + b * b) + (c * c + d * d);
+      }
+    }
+    const float rstd = __builtin_amdgcn_rsqf(wave_sum(q) * inv_n + eps);
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int j = lane + 64 * k;
+      if (j < g.C) {
+        const float4 gm = gamma[j], bt = beta[j];
+        out[row * g.C + j] = make_float4((v[k].x - mean) * rstd * gm.x + bt.x, (v[k].y - mean) * rstd * gm.y + bt.y,
+                                         (v[k].z - mean) * rstd * gm.z + bt.z, (v[k].w - mean) * rstd * gm.w + bt.w);
+      }
+    }
+    if (lane == 0) { mu_out[row] = mean; rstd_out[row] = rstd; }
+  }
+}
+
+// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma;  ws[wave][0: dgamma | 4C: dbeta]
+template <int NV>
+__global__ __launch_bounds__(256) void patch_merge_ln_bwd_kernel(const float4* __restrict__ dy, const float4* __restrict__ x,
+                                                                 const float4* __restrict__ gamma, const float* __restrict__ mu_in,
+                                                                 const float* __restrict__ rstd_in, float4* __restrict__ dinp,
+                                                                 float4* __restrict__ ws, int64_t nrows, PmGeom g) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave_global = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+  const float inv_n = 1.f / (4 * g.C);
+  float4 ag[NV], ab[NV];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) { ag[k] = make_float4(0.f, 0.f, 0.f, 0.f); ab[k] = ag[k]; }
+  for (int64_t row = wave_global; row < nrows; row += nwaves) {
+    const float mean = mu_in[row], rstd = rstd_in[row];
+    float4 xh[NV], gg[NV];
+    int64_t src[NV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int j = lane + 64 * k;
+      if (j < g.C) {
+        src[k] = pm_src(g, row, j);
+        const float4 xv = x[src[k]], d = dy[row * g.C + j], gm = gamma[j];
+        xh[k] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
+        gg[k] = make_float4(d.x * gm.x, d.y * gm.y, d.z * gm.z, d.w * gm.w);
+        s1 += (gg[k].x + gg[k].y) + (gg[k].z + gg[k].w);
+        s2 += (gg[k].x * xh[k].x + gg[k].y * xh[k].y) + (gg[k].z * xh[k].z + gg[k].w * xh[k].w);
+        ag[k].x = fmaf(d.x, xh[k].x, ag[k].x); ag[k].y = fmaf(d.y, xh[k].y, ag[k].y);
+        ag[k].z = fmaf(d.z, xh[k].z, ag[k].z); ag[k].w = fmaf(d.w, xh[k].w, ag[k].w);
+        ab[k].x += d.x; ab[k].y += d.y; ab[k].z += d.z; ab[k].w += d.w;
+      } else {
+        src[k] = 0; xh[k] = make_float4(0.f, 0.f, 0.f, 0.f); gg[k] = xh[k];
+      }
+    }
+    const float m1 = wave_sum(s1) * inv_n, m2 = wave_sum(s2) * inv_n;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      if (lane + 64 * k < g.C)
+        dinp[src[k]] = make_float4(rstd * (gg[k].x - m1 - xh[k].x * m2), rstd * (gg[k].y - m1 - xh[k].y * m2),
+                                   rstd * (gg[k].z - m1 - xh[k].z * m2), rstd * (gg[k].w - m1 - xh[k].w * m2));
+    }
+  }
+  float4* wrow = ws + wave_global * 2 * g.C;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int j = lane + 64 * k;
+    if (j < g.C) { wrow[j] = ag[k]; wrow[g.C + j] = ab[k]; }
+  }
+}
+
+inline int pm_grid(int64_t nrows) {   // >= 4 rows per wavefront, at most 256 workgroups (= 1024 partial dgamma/dbeta rows)
+  int64_t b = (nrows + 15) / 16;
+  return (int)(b < 1 ? 1 : (b > 256 ? 256 : b));
+}
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+}  // namespace
+
+extern "C" {
+
+int mm_patch_merge_ln_supported(int C) { return (C > 0 && C % 4 == 0 && C <= 512) ? 1 : 0; }
+int mm_patch_merge_ln_rows(int batch, int H, int W) { return 4 * pm_grid((int64_t)batch * (H / 2) * (W / 2)); }
+
+#define MM_PM_DISPATCH(KERNEL, ...)                                                                                   \
+  do {                                                                                                                \
+    const int nv = (g.C + 63) / 64;                                                                                   \
+    const dim3 grid(pm_grid(nrows)), block(256);                                                                      \
+    if (nv <= 1) hipLaunchKernelGGL(KERNEL<1>, grid, block, 0, s, __VA_ARGS__);                                       \
+    else if (nv <= 2) hipLaunchKernelGGL(KERNEL<2>, grid, block, 0, s, __VA_ARGS__);                                  \
+    else if (nv <= 4) hipLaunchKernelGGL(KERNEL<4>, grid, block, 0, s, __VA_ARGS__);                                  \
+    else hipLaunchKernelGGL(KERNEL<8>, grid, block, 0, s, __VA_ARGS__);                                               \
+  } while (0)
+
+int mm_patch_merge_ln_fwd(const float* x, const float* gamma, const float* beta, float eps, float* out, float* mu, float* rstd,
+                          int batch, int H, int W, int C, void* stream) {
+  if (!x || !gamma || !beta || !out || !mu || !rstd) return MM_ERR_NULL;
+  if (batch <= 0 || H < 2 || W < 2 || C <= 0) return MM_ERR_SHAPE;
+  if (!mm_patch_merge_ln_supported(C)) return MM_ERR_UNSUPPORTED;
+  if (!al16(x) || !al16(gamma) || !al16(beta) || !al16(out)) return MM_ERR_ALIGN;
+  const PmGeom g{H, W, C, H / 2, W / 2, C / 4};
+  const int64_t nrows = (int64_t)batch * g.h2 * g.w2;
+  hipStream_t s = (hipStream_t)stream;
+  MM_PM_DISPATCH(patch_merge_ln_fwd_kernel, (const float4*)x, (const float4*)gamma, (const float4*)beta, eps, (float4*)out, mu, rstd,
+                 nrows, g);
+  return (int)hipGetLastError();
+}
+
+int mm_patch_merge_ln_bwd(const float* dy, const float* x, const float* gamma, const float* mu, const float* rstd, float* dinp,
+                          float* ws, int batch, int H, int W, int C, void* stream) {
+  if (!dy || !x || !gamma || !mu || !rstd || !dinp || !ws) return MM_ERR_NULL;
+  if (batch <= 0 || H < 2 || W < 2 || C <= 0) return MM_ERR_SHAPE;
+  if (!mm_patch_merge_ln_supported(C)) return MM_ERR_UNSUPPORTED;
+  if (!al16(dy) || !al16(x) || !al16(gamma) || !al16(dinp) || !al16(ws)) return MM_ERR_ALIGN;
+  const PmGeom g{H, W, C, H / 2, W / 2, C / 4};
+  const int64_t nrows = (int64_t)batch * g.h2 * g.w2;
+  hipStream_t s = (hipStream_t)stream;
+  MM_PM_DISPATCH(patch_merge_ln_bwd_kernel, (const float4*)dy, (const float4*)x, (const float4*)gamma, mu, rstd, (float4*)dinp,
+                 (float4*)ws, nrows, g);
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"

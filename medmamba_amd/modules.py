@@ -25,13 +25,14 @@ import torch.nn.functional as F
 import torch.utils.checkpoint as checkpoint
 
 from . import _lib
-from .ops import (PointwiseConvFn, block_split, conv2d_bias, dwconv_silu_cross, in_proj_cf, out_proj_cf, shuffle_residual,
+from .ops import (PointwiseConvFn, block_split, block_split_infer, conv2d_bias, patch_merge_ln, patch_merge_ln_supported, dwconv_silu_cross, in_proj_cf, out_proj_cf, shuffle_residual,
                   ss2d_conv_core, ss2d_core)
 from .selective_scan_interface import CROSS_SCAN_K_OF_G, cross_scan_fn, selective_scan_fn
 
 trunc_normal_ = nn.init.trunc_normal_   # timm.layers.trunc_normal_ == torch.nn.init.trunc_normal_
 
 _TWO_STREAMS = __import__("os").environ.get("MM_TWO_STREAMS", "1") == "1"   # MM_TWO_STREAMS=0: single-stream blocks
+_FOLD_BN = __import__("os").environ.get("MM_FOLD_BN", "1") == "1"         # MM_FOLD_BN=0: eval() keeps the BatchNorm launches
 _SIDE_STREAMS = {}
 # images with at least this many positions start the side stream when the scan kernel is queued (see SS_Conv_SSM.forward)
 _LATE_SIDE_MIN_L = int(__import__("os").environ.get("MM_LATE_SIDE_MIN_L", "2048"))
@@ -130,6 +131,12 @@ class PatchMerging2D(nn.Module):
         if (W % 2 != 0) or (H % 2 != 0):
             print(f"Warning, x.shape {x.shape} is not match even ===========", flush=True)
         h2, w2 = H // 2, W // 2
+        nm = self.norm
+        if (x.is_cuda and h2 > 0 and w2 > 0 and type(nm) is nn.LayerNorm and nm.elementwise_affine and nm.bias is not None
+                and tuple(nm.normalized_shape) == (4 * C,) and x.dtype == torch.float32 and not _has_hooks(self)
+                and patch_merge_ln_supported(C)):
+            # gather + LayerNorm(4C) in one HIP pass each way (the gathered tensor never exists); :117 is the GEMM below
+            return self.reduction(patch_merge_ln(x, nm.weight, nm.bias, nm.eps))
         x = x[:, :2 * h2, :2 * w2, :].reshape(B, h2, 2, w2, 2, C)
         # reference channel order: (row even, col even), (row odd, col even), (row even, col odd), (row odd, col odd)
         x = x.permute(0, 1, 3, 4, 2, 5).reshape(B, h2, w2, 4 * C)
@@ -333,6 +340,83 @@ class SS_Conv_SSM(nn.Module):
             nn.ReLU(),
         )
 
+    # ---- inference: BatchNorm folded into its neighbours (consumers: test.py:76-108, app_streamlit_demo.py) ----
+    def _foldable(self):
+        m = list(self.conv33conv33conv11)
+        kinds = (nn.BatchNorm2d, nn.Conv2d, nn.BatchNorm2d, nn.ReLU, nn.Conv2d, nn.BatchNorm2d, nn.ReLU, nn.Conv2d, nn.ReLU)
+        if len(m) != len(kinds) or not all(isinstance(a, k) for a, k in zip(m, kinds)):
+            return False
+        bns, convs = (m[0], m[2], m[5]), (m[1], m[4], m[7])
+        ok_bn = all(b.track_running_stats and b.running_mean is not None and b.affine for b in bns)
+        ok_cv = all(c.groups == 1 and c.padding_mode == "zeros" and c.stride == (1, 1) and c.dilation == (1, 1) and c.bias is not None
+                    for c in convs) and _is_pointwise(m[7])
+        return ok_bn and ok_cv
+
+    def _eval_fold(self):
+        """Eval-mode constants of the conv branch (MedMamba.py:338-346) with every BatchNorm2d folded away, computed in
+        fp64 and cast once:  BN1 -> per-channel affine applied while the block prologue transposes the left half (before the
+        first conv's zero padding: exact at the border);  conv -> BN2 / conv -> BN3 -> into the conv's weights and bias.
+        Cached per block; any in-place change of a parameter or running statistic (optimizer step, load_state_dict, a
+        training pass) bumps that tensor's version counter and rebuilds it."""
+        m = self.conv33conv33conv11
+        tensors = [m[0].weight, m[0].bias, m[0].running_mean, m[0].running_var, m[1].weight, m[1].bias, m[2].weight, m[2].bias,
+                   m[2].running_mean, m[2].running_var, m[4].weight, m[4].bias, m[5].weight, m[5].bias, m[5].running_mean,
+                   m[5].running_var]
+        key = tuple((t.data_ptr(), t._version) for t in tensors)
+        cache = getattr(self, "_fold_cache", None)
+        if cache is not None and cache[0] == key:
+            return cache[1]
+
+        def affine(bn):
+            s = bn.weight.detach().double() / torch.sqrt(bn.running_var.double() + bn.eps)
+            return s, bn.bias.detach().double() - bn.running_mean.double() * s
+
+        def fold_conv(conv, bn):
+            s, t = affine(bn)
+            w = (conv.weight.detach().double() * s[:, None, None, None]).float().contiguous()
+            return w, (conv.bias.detach().double() * s + t).float().contiguous()
+
+        s1, t1 = affine(m[0])
+        fold = dict(left_affine=torch.cat([s1, t1]).float().contiguous(), a=fold_conv(m[1], m[2]), b=fold_conv(m[4], m[5]),
+                    pad_a=m[1].padding, pad_b=m[4].padding)
+        self._fold_cache = (key, fold)
+        return fold
+
+    @staticmethod
+    def _conv_relu(x, w, b, padding):
+        """conv + bias + ReLU as ONE MIOpen fusion plan where this PyTorch build exposes it (inference only)."""
+        try:
+            return torch.ops.aten.miopen_convolution_relu(x, w, b, [1, 1], list(padding), [1, 1], 1)
+        except (RuntimeError, AttributeError):
+            return F.relu_(F.conv2d(x, w, b, padding=padding))
+
+    def _forward_infer(self, input):
+        """eval() + no_grad: 3 BatchNorm, 2 bias and 2 ReLU launches of the conv branch disappear (folded as _eval_fold says;
+        the trailing ReLU is applied by shuffle_residual as in training)."""
+        fold = self._eval_fold()
+        conv = self.conv33conv33conv11
+        left, right_n = block_split_infer(input, self.ln_1.weight, self.ln_1.bias, self.ln_1.eps, fold["left_affine"])
+
+        def conv_body(t):
+            t = self._conv_relu(t, *fold["a"], fold["pad_a"])
+            t = self._conv_relu(t, *fold["b"], fold["pad_b"])
+            return PointwiseConvFn.apply(t, conv[7].weight, conv[7].bias)         # pre-activation of the trailing ReLU
+
+        if _TWO_STREAMS:
+            main = torch.cuda.current_stream()
+            side = _side_stream(input.device)
+            left.record_stream(side)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                left = conv_body(left)
+            x_cf = self.self_attention.forward_cf(right_n)
+            main.wait_stream(side)
+            left.record_stream(main)
+        else:
+            x_cf = self.self_attention.forward_cf(right_n)
+            left = conv_body(left)
+        return shuffle_residual(left, x_cf, input, channel_first=True, ssm_scale=None, left_relu=True)
+
     def forward_modules(self, input):
         """MedMamba.py:349-357 module by module (hooks on any sub-module fire; used only when hooks are present)."""
         left, right = input.chunk(2, dim=-1)
@@ -343,6 +427,11 @@ class SS_Conv_SSM(nn.Module):
     def forward(self, input):
         if _has_hooks(self) or not isinstance(self.drop_path, DropPath):
             return self.forward_modules(input)
+        ln_ok = isinstance(self.ln_1, nn.LayerNorm) and self.ln_1.elementwise_affine and self.ln_1.bias is not None \
+            and input.shape[-1] % 2 == 0 and input.shape[-1] // 2 <= 512
+        if (_FOLD_BN and not self.training and not torch.is_grad_enabled() and input.is_cuda and ln_ok and self._foldable()
+                and not any(bn.training for bn in (self.conv33conv33conv11[0], self.conv33conv33conv11[2], self.conv33conv33conv11[5]))):
+            return self._forward_infer(input)
         if isinstance(self.ln_1, nn.LayerNorm) and self.ln_1.elementwise_affine and self.ln_1.bias is not None \
                 and input.shape[-1] % 2 == 0 and input.shape[-1] // 2 <= 512:     # block_split keeps a row in registers
             # chunk + permute(0,3,1,2).contiguous() + ln_1 (MedMamba.py:350-352) in one fused HIP prologue

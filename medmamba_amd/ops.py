@@ -540,7 +540,7 @@ class BlockSplitFn(torch.autograd.Function):
         mu = torch.empty((B * P,), device=dev, dtype=torch.float32)
         rstd = torch.empty((B * P,), device=dev, dtype=torch.float32)
         with _lib.device_guard(dev):
-            rc = _lib.lib().mm_block_split_fwd(inp.data_ptr(), gamma.data_ptr(), beta.data_ptr(), float(eps), left.data_ptr(),
+            rc = _lib.lib().mm_block_split_fwd(inp.data_ptr(), gamma.data_ptr(), beta.data_ptr(), float(eps), None, left.data_ptr(),
                                                rn.data_ptr(), mu.data_ptr(), rstd.data_ptr(), B, P, C2, _stream())
         _lib.check(rc, "mm_block_split_fwd")
         ctx.save_for_backward(inp, gamma, mu, rstd)
@@ -566,6 +566,26 @@ class BlockSplitFn(torch.autograd.Function):
         return dinp, s[:C2], s[C2:], None
 
 
+def block_split_infer(inp, gamma, beta, eps, left_affine):
+    """Inference form of block_split (no autograd): the left half additionally gets the per-channel affine
+    left_affine = [scale C/2 | shift C/2] — the eval-mode BatchNorm2d that opens the conv branch (MedMamba.py:338) — while it
+    is transposed to NCHW.  Returns (left NCHW, LayerNorm(right) NHWC)."""
+    _need_hip(inp)
+    inp = inp.float().contiguous()
+    B, H, W, C = inp.shape
+    C2, P = C // 2, H * W
+    dev = inp.device
+    left = torch.empty((B, C2, H, W), device=dev, dtype=torch.float32)
+    rn = torch.empty((B, H, W, C2), device=dev, dtype=torch.float32)
+    stats = torch.empty((2, B * P), device=dev, dtype=torch.float32)
+    with _lib.device_guard(dev):
+        rc = _lib.lib().mm_block_split_fwd(inp.data_ptr(), gamma.data_ptr(), beta.data_ptr(), float(eps), left_affine.data_ptr(),
+                                           left.data_ptr(), rn.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), B, P, C2,
+                                           _stream())
+    _lib.check(rc, "mm_block_split_fwd")
+    return left, rn
+
+
 def block_split(inp, gamma, beta, eps):
     """-> (left NCHW, LayerNorm(right) NHWC, inp for the residual add — use THIS alias as the residual input so that its
     gradient is folded into the backward kernel)."""
@@ -573,3 +593,49 @@ def block_split(inp, gamma, beta, eps):
     if inp.shape[-1] % 2 or inp.shape[-1] // 2 > 512:
         raise NotImplementedError("block_split: even channel count <= 1024 expected")
     return BlockSplitFn.apply(inp, gamma, beta, eps)
+
+
+class PatchMergeLNFn(torch.autograd.Function):
+    """PatchMerging2D's gather + LayerNorm(4C) (MedMamba.py:93-116) in one kernel each way: x (B, H, W, C) NHWC ->
+    (B, H//2, W//2, 4C) normalised rows (the Linear of :117 follows as a plain GEMM).  The backward writes d(x) straight into
+    the gathered positions; for odd H / W the cropped row / column gets zeros (MedMamba.py:97-111)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        x, gamma, beta = x.float().contiguous(), gamma.float().contiguous(), beta.float().contiguous()
+        B, H, W, C = x.shape
+        h2, w2 = H // 2, W // 2
+        dev = x.device
+        out = torch.empty((B, h2, w2, 4 * C), device=dev, dtype=torch.float32)
+        stats = torch.empty((2, B * h2 * w2), device=dev, dtype=torch.float32)
+        with _lib.device_guard(dev):
+            rc = _lib.lib().mm_patch_merge_ln_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), float(eps), out.data_ptr(),
+                                                  stats[0].data_ptr(), stats[1].data_ptr(), B, H, W, C, _stream())
+        _lib.check(rc, "mm_patch_merge_ln_fwd")
+        ctx.save_for_backward(x, gamma, stats)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, stats = ctx.saved_tensors
+        B, H, W, C = x.shape
+        dev = x.device
+        dy = dy.float().contiguous()
+        lib = _lib.lib()
+        dinp = (torch.zeros_like(x) if (H % 2 or W % 2) else torch.empty_like(x))
+        ws = torch.empty((lib.mm_patch_merge_ln_rows(B, H, W), 2, 4 * C), device=dev, dtype=torch.float32)
+        with _lib.device_guard(dev):
+            rc = lib.mm_patch_merge_ln_bwd(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(),
+                                           dinp.data_ptr(), ws.data_ptr(), B, H, W, C, _stream())
+        _lib.check(rc, "mm_patch_merge_ln_bwd")
+        s = ws.sum(0)
+        return dinp, s[0], s[1], None
+
+
+def patch_merge_ln_supported(C):
+    return bool(_lib.lib().mm_patch_merge_ln_supported(int(C)))
+
+
+def patch_merge_ln(x, gamma, beta, eps):
+    _need_hip(x)
+    return PatchMergeLNFn.apply(x, gamma, beta, eps)

@@ -356,3 +356,53 @@ def test_wide_block_beyond_block_split_limit():
     y2 = blk.forward_modules(x.detach())
     _close(y, y2.detach().cpu().numpy(), 2e-4, "y")
     assert torch.isfinite(x.grad).all()
+
+
+def test_eval_path_with_folded_batchnorm(monkeypatch):
+    """eval() + no_grad folds the three BatchNorm2d of the conv branch (MedMamba.py:338-346) into the block
+    prologue / the conv weights (fp64, cast once).  Same values as the reference fixture and as the unfolded path; a hooked
+    block (Grad-CAM, test.py:101) and a grad-enabled eval pass keep the module-by-module / unfolded routes; changed
+    statistics rebuild the fold."""
+    from medmamba_amd import modules
+    fx = load_golden("block_c16.npz")
+    blk = modules.SS_Conv_SSM(hidden_dim=16, drop_path=0.0, norm_layer=torch.nn.LayerNorm)
+    blk.load_state_dict(split_sd(fx))
+    blk.to(DEV).eval()
+    x = torch.from_numpy(fx["x"]).to(DEV)
+    calls = []
+    orig = modules.SS_Conv_SSM._forward_infer
+    monkeypatch.setattr(modules.SS_Conv_SSM, "_forward_infer", lambda self, inp: (calls.append(1), orig(self, inp))[1])
+    with torch.no_grad():
+        y = blk(x)
+    assert calls == [1]
+    _close(y, fx["y_eval"], 5e-5, "folded vs reference fixture")
+    y_unfolded = blk(x)                                   # grad enabled -> the unfolded autograd path
+    assert calls == [1]
+    _close(y, y_unfolded.detach().cpu().numpy(), 2e-5, "folded vs unfolded")
+    # statistics change (a training pass) -> the cached fold is rebuilt
+    blk.train()
+    blk(torch.randn_like(x) * 3 + 1)
+    blk.eval()
+    with torch.no_grad():
+        y2 = blk(x)
+        monkeypatch.setattr(modules, "_FOLD_BN", False)
+        y2_ref = blk(x)
+    assert float((y2 - y).abs().max()) > 1e-4            # the running statistics really moved
+    _close(y2, y2_ref.cpu().numpy(), 2e-5, "refolded vs unfolded")
+    monkeypatch.setattr(modules, "_FOLD_BN", True)
+    # hooks: module-by-module path, hook fires, same values
+    seen = []
+    h = blk.conv33conv33conv11[-2].register_forward_hook(lambda m, i, o: seen.append(o.shape))
+    with torch.no_grad():
+        y3 = blk(x)
+    h.remove()
+    assert len(seen) == 1 and len(calls) == 2
+    _close(y3, y2_ref.cpu().numpy(), 2e-5, "hooked vs unfolded")
+    # the whole tiny model in inference mode against its fixture
+    fxm = load_golden("vssm_tiny.npz")
+    net = modules.VSSM(num_classes=3, depths=[int(v) for v in fxm["depths"]], dims=[int(v) for v in fxm["dims"]], drop_path_rate=0.0)
+    net.load_state_dict(split_sd(fxm))
+    net.to(DEV).eval()
+    with torch.no_grad():
+        _close(net(torch.from_numpy(fxm["x"]).to(DEV)), fxm["logits_eval"], 1e-4, "tiny VSSM logits, folded")
+    assert len(calls) > 2
