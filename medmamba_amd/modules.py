@@ -352,6 +352,16 @@ class SS_Conv_SSM(nn.Module):
                     for c in convs) and _is_pointwise(m[7])
         return ok_bn and ok_cv
 
+    def train(self, mode: bool = True):
+        # MIOpen's training-mode BatchNorm updates running_mean / running_var without bumping their version counters, so the
+        # fold below cannot see that change: every train() / eval() switch drops it (it is rebuilt on the next inference pass)
+        self._fold_cache = None
+        return super().train(mode)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self._fold_cache = None
+        return super()._load_from_state_dict(*args, **kwargs)
+
     def _eval_fold(self):
         """Eval-mode constants of the conv branch (MedMamba.py:338-346) with every BatchNorm2d folded away, computed in
         fp64 and cast once:  BN1 -> per-channel affine applied while the block prologue transposes the left half (before the

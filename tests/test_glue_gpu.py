@@ -4,6 +4,8 @@ import numpy as np
 import pytest
 import torch
 
+from conftest import load_golden
+
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
@@ -267,8 +269,6 @@ def test_patch_merge_ln_vs_reference_fixture(case):
     m = PatchMerging2D(dim=C)
     m.load_state_dict({k[3:]: torch.from_numpy(v.copy()) for k, v in fx.items() if k.startswith("sd/")})
     m.to(DEV)
-    used = []
-    orig = ops.PatchMergeLNFn.forward
     y = m(x)
     want = fx[f"y_{case}"]
     assert np.abs(y.detach().cpu().numpy() - want).max() <= 5e-6 * max(1.0, np.abs(want).max())
