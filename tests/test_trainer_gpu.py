@@ -40,10 +40,10 @@ def test_synthetic_training_checkpoints_and_resume(tmp_path):
         vb = cb["model_state_dict"][k]
         if va.dtype.is_floating_point:
             assert float((va - vb).abs().max()) <= 2 * lr * resumed_steps + 1e-4 * float(va.abs().max()), k
-    w = "layers.0.blocks.0.self_attention.in_proj.weight"
-    assert float((ca["model_state_dict"][w] - cb["model_state_dict"][w]).abs().max()) <= 5e-5
         else:
             assert torch.equal(va, vb), k                            # BatchNorm step counters
+    w = "layers.0.blocks.0.self_attention.in_proj.weight"
+    assert float((ca["model_state_dict"][w] - cb["model_state_dict"][w]).abs().max()) <= 5e-5
     sa, sb = ca["optimizer_state_dict"]["state"], cb["optimizer_state_dict"]["state"]
     assert len(sa) == len(sb) and all(float(sa[i]["step"]) == float(sb[i]["step"]) == 6.0 for i in sa)
     bests = [f for f in os.listdir(a) if f.endswith("_best.pth")]
