@@ -67,13 +67,16 @@ __device__ __forceinline__ rsrc_t make_rsrc(const void* base, int64_t bytes) {
 // Time-ordered values of time slots t..t+3 of the row that starts at byte offset `row` of descriptor r.
 // rev: slot t lives at memory position L-1-t (the row is walked backwards; nothing is ever flipped in memory).
 // VEC (L % 4 == 0, 16-B aligned rows): one dwordx4, a quad is entirely inside or outside the row.
-template <bool VEC>
+// MEMORDER (VEC only): return the quad as it lies in memory even for a reversed row (components NOT swapped) — for callers
+// that keep a reversed tile in memory order and walk it backwards themselves (4 v_cndmask per quad saved).
+template <bool VEC, bool MEMORDER = false>
 __device__ __forceinline__ float4 load_quad(rsrc_t r, int row, int t, int L, bool rev, bool rowok) {
   if constexpr (VEC) {
     const bool ok = rowok && t < L;
     const int pos = rev ? L - 4 - t : t;
     const v4u v = __builtin_amdgcn_raw_buffer_load_b128(r, ok ? row + pos * 4 : kOOB, 0, 0);
     const v4f f = __builtin_bit_cast(v4f, v);
+    if constexpr (MEMORDER) return make_float4(f.x, f.y, f.z, f.w);
     return rev ? make_float4(f.w, f.z, f.y, f.x) : make_float4(f.x, f.y, f.z, f.w);
   } else {
     float o[4];
@@ -88,12 +91,12 @@ __device__ __forceinline__ float4 load_quad(rsrc_t r, int row, int t, int L, boo
   }
 }
 
-template <bool VEC>
+template <bool VEC, bool MEMORDER = false>
 __device__ __forceinline__ void store_quad(rsrc_t r, int row, int t, int L, bool rev, bool rowok, float4 v) {
   if constexpr (VEC) {
     const bool ok = rowok && t < L;
     const int pos = rev ? L - 4 - t : t;
-    const v4f f = rev ? (v4f){v.w, v.z, v.y, v.x} : (v4f){v.x, v.y, v.z, v.w};
+    const v4f f = (!MEMORDER && rev) ? (v4f){v.w, v.z, v.y, v.x} : (v4f){v.x, v.y, v.z, v.w};
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, f), r, ok ? row + pos * 4 : kOOB, 0, 0);
   } else {
     const float o[4] = {v.x, v.y, v.z, v.w};

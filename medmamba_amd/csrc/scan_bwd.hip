@@ -16,6 +16,7 @@
 // summed over the waves + flushed one tile later, so the whole tile loop has ONE barrier per tile.
 // Global traffic uses bounds-checked buffer descriptors (mm_common.h) and a register prefetch of the next
 // tile; reversed directions / shared u blocks as in the forward kernel (include/medmamba_hip.h).
+#include <type_traits>
 #include "mm_common.h"
 #include "medmamba_hip.h"
 
@@ -142,12 +143,17 @@ __global__ __launch_bounds__(512) void scan_bwd_kernel(const BwdParams p) {
     const int t = t0 + 4 * q;
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
-      pu[i] = load_quad<VEC>(ru, uoff[i], t, p.L, rev, rvalid[i]);
-      pd[i] = load_quad<VEC>(rd, doff[i], t, p.L, rev, rvalid[i]);
-      pg[i] = load_quad<VEC>(rg, ooff[i], t, p.L, rev, rvalid[i]);
+      pu[i] = load_quad<VEC, VEC>(ru, uoff[i], t, p.L, rev, rvalid[i]);
+      pd[i] = load_quad<VEC, VEC>(rd, doff[i], t, p.L, rev, rvalid[i]);
+      pg[i] = load_quad<VEC, VEC>(rg, ooff[i], t, p.L, rev, rvalid[i]);
     }
-    if (nthreads >= 256) pbc = load_quad<VEC>(bc_which ? rC : rB, bc_off, t0 + 4 * bc_q, p.L, rev, bc_mine);
+    if (nthreads >= 256) pbc = load_quad<VEC, VEC>(bc_which ? rC : rB, bc_off, t0 + 4 * bc_q, p.L, rev, bc_mine);
   };
+  // Reversed directions on the vector path keep their quads in MEMORY order (no per-component selects on loads / stores);
+  // a reversed tile lies mirrored in LDS (time quad q in column QL-1-q, step e in component 3-e) and the loops below
+  // address it through colof() / at() — instantiated for both orders, selected by a wave-uniform branch (scan_fwd.hip).
+  const bool revm = VEC && rev;
+  const int qc = revm ? QL - 1 - q : q;
 
   // flush one buffer of per-wave partial sums (tile starting at t0) to global: sum over the workgroup's waves.
   // (Plain stores into per-wave slabs + this sum replace LDS float atomics: ds_add_f32 costs ~40 ns of the CU's LDS
@@ -199,23 +205,23 @@ __global__ __launch_bounds__(512) void scan_bwd_kernel(const BwdParams p) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const float raw = f4get(pd[i], e) + bv[i];
-        const bool in = rvalid[i] && (t + e < p.L);
+        const bool in = rvalid[i] && (VEC ? t < p.L : t + e < p.L);
         const float v = SP ? softplus_f(raw) : raw;
         (&dl.x)[e] = in ? v : 0.f;
         dDacc[i] = fmaf(f4get(pg[i], e), f4get(pu[i], e), dDacc[i]);
       }
-      const int off = (RPI * i + r) * TS + 4 * q;
+      const int off = (RPI * i + r) * TS + 4 * qc;
       *reinterpret_cast<float4*>(s_u + off) = pu[i];
       *reinterpret_cast<float4*>(s_dl + off) = dl;
       *reinterpret_cast<float4*>(s_g + off) = pg[i];
     }
     if (nthreads >= 256) {
-      if (bc_mine) *reinterpret_cast<float4*>(sBC + ((buf * 2 + bc_which) * kNState + bc_n) * TS + 4 * bc_q) = pbc;
+      if (bc_mine) *reinterpret_cast<float4*>(sBC + ((buf * 2 + bc_which) * kNState + bc_n) * TS + 4 * (revm ? QL - 1 - bc_q : bc_q)) = pbc;
     } else {   // fewer than 4 waves (tiny problems): every thread stages several quads, no prefetch
       for (int idx = tid; idx < 256; idx += nthreads) {
         const int w_ = (idx >> 7) & 1, n_ = (idx >> 3) & 15, q_ = idx & 7;
-        *reinterpret_cast<float4*>(sBC + ((buf * 2 + w_) * kNState + n_) * TS + 4 * q_) =
-            load_quad<VEC>(w_ ? rC : rB, (int)(n_ * (w_ ? p.C_sn : p.B_sn)) * 4, t0 + 4 * q_, p.L, rev, true);
+        *reinterpret_cast<float4*>(sBC + ((buf * 2 + w_) * kNState + n_) * TS + 4 * (revm ? QL - 1 - q_ : q_)) =
+            load_quad<VEC, VEC>(w_ ? rC : rB, (int)(n_ * (w_ ? p.C_sn : p.B_sn)) * 4, t0 + 4 * q_, p.L, rev, true);
       }
     }
     if (tile > 0) issue_loads(t0 - T);
@@ -228,6 +234,10 @@ __global__ __launch_bounds__(512) void scan_bwd_kernel(const BwdParams p) {
     const float* sB = sBC + ((buf * 2 + 0) * kNState + g * NS) * TS;
     const float* sC = sBC + ((buf * 2 + 1) * kNState + g * NS) * TS;
     float* accb = acc_lane + buf * nwaves * 2 * kNState * TS;
+    auto phase2 = [&](auto rvtag) {
+    constexpr bool RV = decltype(rvtag)::value;
+    auto colof = [](int to) { return RV ? T - 4 - to : to; };                  // LDS column (floats) of time offset `to`
+    auto at = [](const float4& v, int e) { return f4get(v, RV ? 3 - e : e); };   // time step e of a quad
     for (int sub = nsub - 1; sub >= 0; --sub) {
       const int ts = sub * kChunk;
       // 4-step groups of this sub-tile that hold real time steps (the last sub-tile of a sequence whose length is not a
@@ -247,19 +257,19 @@ __global__ __launch_bounds__(512) void scan_bwd_kernel(const BwdParams p) {
       for (int tq = 0; tq < 4; ++tq) {
         if (tq >= ntq) continue;
         const int to = ts + 4 * tq;
-        const float4 dl4 = *reinterpret_cast<const float4*>(s_dl + c * TS + to);
-        const float4 u4 = *reinterpret_cast<const float4*>(s_u + c * TS + to);
+        const float4 dl4 = *reinterpret_cast<const float4*>(s_dl + c * TS + colof(to));
+        const float4 u4 = *reinterpret_cast<const float4*>(s_u + c * TS + colof(to));
         float4 Bv[NS];
 #pragma unroll
-        for (int j = 0; j < NS; ++j) Bv[j] = *reinterpret_cast<const float4*>(sB + j * TS + to);
+        for (int j = 0; j < NS; ++j) Bv[j] = *reinterpret_cast<const float4*>(sB + j * TS + colof(to));
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float dl = f4get(dl4, e), dlu = dl * f4get(u4, e);
+          const float dl = at(dl4, e), dlu = dl * at(u4, e);
 #pragma unroll
           for (int j = 0; j < NS; ++j) {
             const float a = __builtin_amdgcn_exp2f(dl * A2[j]);
             const float prev = (tq == 0 && e == 0) ? x0[j] : xs[4 * tq + e - 1][j];
-            xs[4 * tq + e][j] = fmaf(a, prev, dlu * f4get(Bv[j], e));
+            xs[4 * tq + e][j] = fmaf(a, prev, dlu * at(Bv[j], e));
           }
         }
       }
@@ -268,26 +278,26 @@ __global__ __launch_bounds__(512) void scan_bwd_kernel(const BwdParams p) {
       for (int tq = 3; tq >= 0; --tq) {
         if (tq >= ntq) continue;
         const int to = ts + 4 * tq;
-        const float4 dl4 = *reinterpret_cast<const float4*>(s_dl + c * TS + to);
-        const float4 u4 = *reinterpret_cast<const float4*>(s_u + c * TS + to);
-        const float4 g4 = *reinterpret_cast<const float4*>(s_g + c * TS + to);
+        const float4 dl4 = *reinterpret_cast<const float4*>(s_dl + c * TS + colof(to));
+        const float4 u4 = *reinterpret_cast<const float4*>(s_u + c * TS + colof(to));
+        const float4 g4 = *reinterpret_cast<const float4*>(s_g + c * TS + colof(to));
         float4 Bv[NS], Cv[NS];
 #pragma unroll
         for (int j = 0; j < NS; ++j) {
-          Bv[j] = *reinterpret_cast<const float4*>(sB + j * TS + to);
-          Cv[j] = *reinterpret_cast<const float4*>(sC + j * TS + to);
+          Bv[j] = *reinterpret_cast<const float4*>(sB + j * TS + colof(to));
+          Cv[j] = *reinterpret_cast<const float4*>(sC + j * TS + colof(to));
         }
         float4 du4, ddl4;
 #pragma unroll
         for (int e = 3; e >= 0; --e) {
           const int tt = 4 * tq + e;
-          const float dl = f4get(dl4, e), ut = f4get(u4, e), gt = f4get(g4, e);
+          const float dl = at(dl4, e), ut = at(u4, e), gt = at(g4, e);
           const float dlu = dl * ut;
           float s1 = 0.f, s2 = 0.f;
           float v[8];                                  // dB partials [0..3], dC partials [4..7]
 #pragma unroll
           for (int j = 0; j < NS; ++j) {
-            const float Bn = f4get(Bv[j], e), Cn = f4get(Cv[j], e);
+            const float Bn = at(Bv[j], e), Cn = at(Cv[j], e);
             const float xc = xs[tt][j];
             const float gxt = fmaf(Cn, gt, gx[j]);
             const float w = fmaf(-dlu, Bn, xc);        // = a_t * x_{t-1}
@@ -312,8 +322,8 @@ __global__ __launch_bounds__(512) void scan_bwd_kernel(const BwdParams p) {
           }
           // d softplus / d raw = sigmoid(raw) = 1 - exp(-delta')  (series for tiny delta' keeps it relative-accurate)
           const float sg = SP ? (dl < 9.765625e-4f ? dl * (1.f - 0.5f * dl) : 1.f - __builtin_amdgcn_exp2f(-dl * kLog2e)) : 1.f;
-          (&ddl4.x)[e] = pa * sg;
-          (&du4.x)[e] = fmaf(Dc, gt, pa);
+          (&ddl4.x)[RV ? 3 - e : e] = pa * sg;
+          (&du4.x)[RV ? 3 - e : e] = fmaf(Dc, gt, pa);
           // dB/dC: 8 values x 16 lanes -> one value per lane (halving butterfly), then one LDS atomic per lane
           {
             // levels 1 and 2 (8 -> 4 -> 2 values) pair lanes that sit in different DPP banks (bit 2: i <-> i^7 by
@@ -343,22 +353,28 @@ __global__ __launch_bounds__(512) void scan_bwd_kernel(const BwdParams p) {
             if (!(c & 2)) accb[to + e] = w1;       // this wave's own slab: a plain ds_write_b32
           }
         }
-        if (g == 0) *reinterpret_cast<float4*>(s_dl + c * TS + to) = ddl4;
-        if (g == 2) *reinterpret_cast<float4*>(s_u + c * TS + to) = du4;
+        if (g == 0) *reinterpret_cast<float4*>(s_dl + c * TS + colof(to)) = ddl4;
+        if (g == 2) *reinterpret_cast<float4*>(s_u + c * TS + colof(to)) = du4;
       }
+    }
+    };   // phase2
+    if constexpr (VEC) {
+      if (revm) phase2(std::true_type{}); else phase2(std::false_type{});
+    } else {
+      phase2(std::false_type{});
     }
 
     // ---- phase 3: private LDS -> global
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
       const int t = t0 + 4 * q;
-      const int off = (RPI * i + r) * TS + 4 * q;
+      const int off = (RPI * i + r) * TS + 4 * qc;
       const float4 vdu = *reinterpret_cast<const float4*>(s_u + off);
       const float4 vdd = *reinterpret_cast<const float4*>(s_dl + off);
-      store_quad<VEC>(rdu, ooff[i], t, p.L, rev, rvalid[i], vdu);
-      store_quad<VEC>(rdd, ooff[i], t, p.L, rev, rvalid[i], vdd);
+      store_quad<VEC, VEC>(rdu, ooff[i], t, p.L, rev, rvalid[i], vdu);
+      store_quad<VEC, VEC>(rdd, ooff[i], t, p.L, rev, rvalid[i], vdd);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) dbacc[i] += (rvalid[i] && t + e < p.L) ? f4get(vdd, e) : 0.f;
+      for (int e = 0; e < 4; ++e) dbacc[i] += (rvalid[i] && (VEC ? t < p.L : t + e < p.L)) ? f4get(vdd, e) : 0.f;
     }
   }
   __syncthreads();

@@ -21,6 +21,7 @@
 // count vmcnt exactly.  Padded steps are identity steps (delta' = 0 -> a = 1, b = 0).
 // Cost per state-step: v_mul, v_exp_f32, v_mul, v_fma, v_fma (measured: ~1.05 ns per VALU issue slot per
 // SIMD with >= 2 waves; the transcendental overlaps other VALU) — no parallel-scan work inflation.
+#include <type_traits>
 #include "mm_common.h"
 #include "medmamba_hip.h"
 
@@ -145,20 +146,26 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(const FwdParams p) {
     const int t = t0 + 4 * q;
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
-      pu[i] = load_quad<VEC>(ru, uoff[i], t, p.L, rev, rvalid[i]);
-      pd[i] = load_quad<VEC>(rd, doff[i], t, p.L, rev, rvalid[i]);
+      pu[i] = load_quad<VEC, VEC>(ru, uoff[i], t, p.L, rev, rvalid[i]);
+      pd[i] = load_quad<VEC, VEC>(rd, doff[i], t, p.L, rev, rvalid[i]);
     }
     if constexpr (!LEAN) {
 #pragma unroll
-      for (int k = 0; k < NBC; ++k) pbc[k] = load_quad<VEC>((k >= NBC / 2) ? rC : rB, bcoff[k], t, p.L, rev, true);
+      for (int k = 0; k < NBC; ++k) pbc[k] = load_quad<VEC, VEC>((k >= NBC / 2) ? rC : rB, bcoff[k], t, p.L, rev, true);
     }
   };
+  // Reversed directions on the vector path: quads stay in MEMORY order all the way (no per-component selects on loads
+  // and stores: ~16 v_cndmask per 4-step group saved); a reversed tile lies mirrored in LDS — time quad q in column
+  // QL-1-q, time step e of a quad in component 3-e — and the recurrence walks it backwards (instantiated for both orders,
+  // selected by a wave-uniform branch).  The dword path (VEC = false) keeps everything in time order.
+  const bool revm = VEC && rev;
+  const int qc = revm ? QL - 1 - q : q;               // LDS column of this lane's staged quads
 
   float4 yreg[NLD];
   auto store_tile = [&](int t0) {
     const bool st_en = !(p.dbg & 1);   // folded into the range check: no branch, so vmcnt stays countable
 #pragma unroll
-    for (int i = 0; i < NLD; ++i) store_quad<VEC>(ro, ooff[i], t0 + 4 * q, p.L, rev, rvalid[i] && st_en, yreg[i]);
+    for (int i = 0; i < NLD; ++i) store_quad<VEC, VEC>(ro, ooff[i], t0 + 4 * q, p.L, rev, rvalid[i] && st_en, yreg[i]);
   };
 
   issue_loads(0);
@@ -174,12 +181,13 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(const FwdParams p) {
       for (int e = 0; e < 4; ++e) {
         const float raw = f4get(pd[i], e) + bv[i];
         float v = SP ? softplus_f(raw) : raw;
-        v = (rvalid[i] && t + e < p.L) ? v : 0.f;     // identity step outside the sequence / channel range
+        // identity step outside the sequence / channel range (vector path: L % 4 == 0, a quad is inside or outside as a whole)
+        v = (rvalid[i] && (VEC ? t < p.L : t + e < p.L)) ? v : 0.f;
         (&dl.x)[e] = v;
         (&du.x)[e] = v * f4get(pu[i], e);
       }
       uD[i] = make_float4(pu[i].x * Dv[i], pu[i].y * Dv[i], pu[i].z * Dv[i], pu[i].w * Dv[i]);
-      const int off = (RPI * i + r) * kTileStride + 4 * q;
+      const int off = (RPI * i + r) * kTileStride + 4 * qc;
       *reinterpret_cast<float4*>(s_dl + off) = dl;
       *reinterpret_cast<float4*>(s_du + off) = du;
     }
@@ -187,8 +195,8 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(const FwdParams p) {
     for (int k = 0; k < NBC; ++k) {
       const int n = (k % (NBC / 2)) * RPI + r;
       const bool isC = k >= NBC / 2;
-      const float4 v = LEAN ? load_quad<VEC>(isC ? rC : rB, bcoff[k], t0 + 4 * q, p.L, rev, true) : pbc[LEAN ? 0 : k];
-      *reinterpret_cast<float4*>(s_bc + ((isC ? kNState : 0) + n) * kTileStride + 4 * q) = v;
+      const float4 v = LEAN ? load_quad<VEC, VEC>(isC ? rC : rB, bcoff[k], t0 + 4 * q, p.L, rev, true) : pbc[LEAN ? 0 : k];
+      *reinterpret_cast<float4*>(s_bc + ((isC ? kNState : 0) + n) * kTileStride + 4 * qc) = v;
     }
     // the previous tile's stores go out here: older than the loads issued next, so the wait for those
     // loads (one recurrence later) retires them for free and every path sees the same vmcnt picture
@@ -203,18 +211,22 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(const FwdParams p) {
     const float* sB = s_bc + (g * NS) * kTileStride;
     const float* sC = s_bc + (kNState + g * NS) * kTileStride;
     struct Ops { float4 dl4, du4, Bv[NS], Cv[NS]; };
+    auto phase2 = [&](auto rvtag) {
+    constexpr bool RV = decltype(rvtag)::value;          // mirrored tile: time group tg in column QL-1-tg, step e in component 3-e
     auto load_ops = [&](int tg) {
       Ops o;
-      o.dl4 = *reinterpret_cast<const float4*>(s_dl + c * kTileStride + 4 * tg);
-      o.du4 = *reinterpret_cast<const float4*>(s_du + c * kTileStride + 4 * tg);
+      const int col = RV ? QL - 1 - tg : tg;
+      o.dl4 = *reinterpret_cast<const float4*>(s_dl + c * kTileStride + 4 * col);
+      o.du4 = *reinterpret_cast<const float4*>(s_du + c * kTileStride + 4 * col);
 #pragma unroll
       for (int j = 0; j < NS; ++j) {
-        o.Bv[j] = *reinterpret_cast<const float4*>(sB + j * kTileStride + 4 * tg);
-        o.Cv[j] = *reinterpret_cast<const float4*>(sC + j * kTileStride + 4 * tg);
+        o.Bv[j] = *reinterpret_cast<const float4*>(sB + j * kTileStride + 4 * col);
+        o.Cv[j] = *reinterpret_cast<const float4*>(sC + j * kTileStride + 4 * col);
       }
       return o;
     };
     auto compute = [&](const Ops& o, int tg) {
+      auto at = [](const float4& v, int e) { return f4get(v, RV ? 3 - e : e); };
       // all 4*NS decay factors of the group first, then the dependent FMA chains: a v_exp_f32 result that is consumed
       // 2-3 instructions later stalls a wave that has no partner on its SIMD (the transcendental pipe takes 8 cycles
       // per instruction, but it runs beside the VALU) — keeping the two blocks apart removes that exposure
@@ -222,21 +234,21 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(const FwdParams p) {
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
-        for (int j = 0; j < NS; ++j) a[e][j] = __builtin_amdgcn_exp2f(f4get(o.dl4, e) * A2[j]);
+        for (int j = 0; j < NS; ++j) a[e][j] = __builtin_amdgcn_exp2f(at(o.dl4, e) * A2[j]);
       __builtin_amdgcn_sched_barrier(0);
       float4 y4;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float du = f4get(o.du4, e);
+        const float du = at(o.du4, e);
         float y = 0.f;
 #pragma unroll
         for (int j = 0; j < NS; ++j) {
-          x[j] = fmaf(a[e][j], x[j], du * f4get(o.Bv[j], e));
-          y = fmaf(x[j], f4get(o.Cv[j], e), y);
+          x[j] = fmaf(a[e][j], x[j], du * at(o.Bv[j], e));
+          y = fmaf(x[j], at(o.Cv[j], e), y);
         }
-        (&y4.x)[e] = group_sum<SG>(y);
+        (&y4.x)[RV ? 3 - e : e] = group_sum<SG>(y);
       }
-      if (g == 0) *reinterpret_cast<float4*>(s_du + c * kTileStride + 4 * tg) = y4;
+      if (g == 0) *reinterpret_cast<float4*>(s_du + c * kTileStride + 4 * (RV ? QL - 1 - tg : tg)) = y4;
       if (p.x_chk != nullptr && ((tg & 3) == 3 || tg == ngroups - 1) && cvalid) {
         const int chunk = (t0 >> 4) + (tg >> 2);   // kChunk = 16 divides both tile sizes
         float* dst = p.x_chk + (((int64_t)b * p.dim + d) * p.nchk + chunk) * kNState + g * NS;
@@ -263,11 +275,17 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(const FwdParams p) {
       __builtin_amdgcn_sched_barrier(0);
     }
     }
+    };   // phase2
+    if constexpr (VEC) {
+      if (revm) phase2(std::true_type{}); else phase2(std::false_type{});
+    } else {
+      phase2(std::false_type{});
+    }
 
     // ---- phase 3: y (+ D*u) LDS -> registers -> global (coalesced like the loads)
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
-      const float4 y = *reinterpret_cast<const float4*>(s_du + (RPI * i + r) * kTileStride + 4 * q);
+      const float4 y = *reinterpret_cast<const float4*>(s_du + (RPI * i + r) * kTileStride + 4 * qc);
       yreg[i] = make_float4(y.x + uD[i].x, y.y + uD[i].y, y.z + uD[i].z, y.w + uD[i].w);
     }
     if constexpr (LEAN) store_tile(t0);
