@@ -160,23 +160,18 @@ __global__ __launch_bounds__(512) void scan_bwd_kernel(const BwdParams p) {
   //  pipe per wave-instruction with 32 active lanes — tools/ubench/lds_rate.cpp — i.e. 8 waves x 1 per step = 320 ns of
   //  every ~540 ns step at the 56x56 stage.)
   auto flush_acc = [&](int buf, int t0) {
-    for (int idx = tid; idx < 256; idx += nthreads) {
-      const int which = idx >> 7, n = (idx >> 3) & 15, qq = idx & 7;
-      const float* a = sAcc + ((buf * nwaves * 2 + which) * kNState + n) * TS + 4 * qq;
-      float4 v = *reinterpret_cast<const float4*>(a);
-      for (int w = 1; w < nwaves; ++w) {
-        const float4 o = *reinterpret_cast<const float4*>(a + w * 2 * kNState * TS);
-        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
-      }
-      float* dst = which ? dCbase + n * p.dC_sn : dBbase + n * p.dB_sn;
-      const int t = t0 + 4 * qq;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int te = t + e;
-        if (te < p.L) {
-          float* pdst = dst + (rev ? p.L - 1 - te : te);
-          if (p.ncw == 1) *pdst = f4get(v, e); else atomicAdd(pdst, f4get(v, e));
-        }
+    // lanes along TIME: a wave-instruction then covers runs of T consecutive dwords of dB / dC rows (128-B segments).  With
+    // one float4 (4 steps) per lane the atomics of one instruction were 16 B apart: every 64-B memory-side atomic request
+    // carried 4 useful dwords (PMC: the dB/dC atomics cost 4x their bytes in WRITE_SIZE, profiles/r2_scan_traffic_pmc.txt).
+    for (int idx = tid; idx < 2 * kNState * T; idx += nthreads) {
+      const int which = idx / (kNState * T), n = (idx / T) % kNState, tt = idx % T;
+      const float* a = sAcc + ((buf * nwaves * 2 + which) * kNState + n) * TS + tt;
+      float v = a[0];
+      for (int w = 1; w < nwaves; ++w) v += a[w * 2 * kNState * TS];
+      const int te = t0 + tt;
+      if (te < p.L) {
+        float* pdst = (which ? dCbase + n * p.dC_sn : dBbase + n * p.dB_sn) + (rev ? p.L - 1 - te : te);
+        if (p.ncw == 1) *pdst = v; else atomicAdd(pdst, v);
       }
     }
   };
@@ -443,13 +438,19 @@ int scan_bwd_launch(const mm_scan_args* a, hipStream_t stream) {
   if (p.dC_sn > snmax) snmax = p.dC_sn;
   if (span >= 0x7ffffff0ll || (int64_t)kNState * snmax * 4 >= 0x7ffffff0ll) return MM_ERR_UNSUPPORTED;
   const int waves_needed = (p.H + CH - 1) / CH;
-  // waves per workgroup: <= 8 (register budget); fewer when (batch, direction) pairs alone cannot fill 256 CUs
-  // with two workgroups each — the price is fp32 atomics on dB/dC from the workgroups that share a direction
-  // (measured, S/Bz=64: 4-wave workgroups are 7-15 % faster than 8-wave ones once a direction needs several anyway)
-  int maxw = (waves_needed <= 8 && (long)a->batch * a->G >= 256) ? 8 : 4;
+  // waves per workgroup (<= 8: register budget).  A direction that fits ONE workgroup (<= 128 channels) gets one when there are
+  // enough (batch, direction) pairs for every CU: dB/dC then leave with plain stores (measured, S/Bz=64 stage 1: 1.51 ms
+  // with 256 x 6 waves vs 1.58-1.65 ms with 512 x 3 waves + atomics).  Otherwise 4-wave workgroups, fewer when the pairs
+  // alone cannot give every CU two workgroups — the price is fp32 atomics on dB/dC from the workgroups that share a
+  // direction (measured: 4-wave workgroups beat 6- and 8-wave ones at stages 2-4: 0.62 vs 0.76 / 0.80 ms, 0.32 vs 0.34 ms)
+  int maxw;
   const int forced = (a->variant >> 16) & 0xff;              // tuning override
   if (forced > 0) maxw = forced > 8 ? 8 : forced;
-  else while (maxw > 2 && (long)a->batch * a->G * ((waves_needed + maxw - 1) / maxw) < 512) maxw >>= 1;
+  else if (waves_needed <= 8 && (long)a->batch * a->G >= 256) maxw = 8;
+  else {
+    maxw = 4;
+    while (maxw > 2 && (long)a->batch * a->G * ((waves_needed + maxw - 1) / maxw) < 512) maxw >>= 1;
+  }
   const int ncw0 = (waves_needed + maxw - 1) / maxw;
   const int waves = (waves_needed + ncw0 - 1) / ncw0;
   p.CW = waves * CH;
