@@ -7,8 +7,9 @@ from medmamba_amd.modules import VSSM, MEDMAMBA_CONFIGS
 dev = torch.device("cuda:0")
 torch.manual_seed(42)
 net = VSSM(num_classes=6, **MEDMAMBA_CONFIGS["S"]).to(dev).train()
-opt = torch.optim.AdamW(net.parameters(), lr=1e-4, weight_decay=1e-4)
-x = torch.randn(64, 3, 224, 224, device=dev); y = torch.randint(0, 6, (64,), device=dev)
+opt = torch.optim.AdamW(net.parameters(), lr=1e-4, weight_decay=1e-4, fused=True)
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+x = torch.randn(B, 3, 224, 224, device=dev); y = torch.randint(0, 6, (B,), device=dev)
 def step():
     opt.zero_grad(set_to_none=True)
     loss = torch.nn.functional.cross_entropy(net(x), y); loss.backward(); opt.step()
