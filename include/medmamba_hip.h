@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MM_ABI_VERSION 13
+#define MM_ABI_VERSION 14
 
 enum mm_status {
   MM_OK = 0,
@@ -143,14 +143,15 @@ int mm_shuffle_residual_bwd(const float* dout, float* dleft, float* dssm, int64_
  *   u2[b,0,d,h*W+w] = u2[b,1,d,w*H+h] = silu(conv(x)[b,d,h,w] + bias[d]).
  * mm_dwconv_silu_cross_bwd: du2 (same plane indexing) [+ du4 or NULL: the scan's per-direction input gradients, 4*D
  *   planes per batch item, plane (b, k*D+d) at du4 + b*du4_sb + (k*D+d)*du4_sd; directions 0,1 add to the row-major image,
- *   2,3 to the column-major one] -> dx planes and per-plane partial sums
- *   ws[(b*D+d)*10 + (0..8: dW[kh][kw], 9: dbias)]  (the caller sums over b). */
+ *   2,3 to the column-major one] -> dx planes and per-(plane, strip) partial sums
+ *   ws[((b*D+d)*S + s)*10 + (0..8: dW[kh][kw], 9: dbias)], S = mm_dwconv_silu_cross_strips(H, W)  (the caller sums over b, s). */
 int mm_dwconv_silu_cross_fwd(const float* x, int64_t x_sb, int64_t x_sd, const float* w, const float* bias, float* u2,
                              int64_t u2_sb, int64_t u2_sd, int batch, int D, int H, int W, void* stream);
-/* 1 if an H x W plane fits the LDS budget of BOTH kernels (they keep whole planes on chip; the backward needs
- * 2*(H+2)*(W+2) + H*(W+1) floats <= 150 KB, i.e. up to about 110 x 110), else 0: the caller then runs the depthwise
- * conv of MedMamba.py:294-295 through its generic convolution and hands both image orders to the scan itself. */
+/* Both kernels work on row strips of a plane (whole plane when it fits 48 KB of LDS, else 32 rows + halo), so there is no
+ * plane-size limit in practice: mm_dwconv_silu_cross_supported is 0 only when a single strip row set cannot fit (W > ~8000).
+ * mm_dwconv_silu_cross_strips(H, W) = number of strips per plane = rows of partial sums per plane in the backward's ws. */
 int mm_dwconv_silu_cross_supported(int H, int W);
+int mm_dwconv_silu_cross_strips(int H, int W);
 int mm_dwconv_silu_cross_bwd(const float* du2, int64_t du2_sb, int64_t du2_sd, const float* du4, int64_t du4_sb, int64_t du4_sd,
                              const float* x, int64_t x_sb, int64_t x_sd,
                              const float* w, const float* bias, float* dx, int64_t dx_sb, int64_t dx_sd, float* ws, int batch,

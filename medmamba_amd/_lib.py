@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "lib", "libmedmamba_hip.so")
 
-ABI_VERSION = 13        # == MM_ABI_VERSION of include/medmamba_hip.h (checked when the library is loaded)
+ABI_VERSION = 14        # == MM_ABI_VERSION of include/medmamba_hip.h (checked when the library is loaded)
 _f32p = ctypes.c_void_p
 _i64 = ctypes.c_int64
 
@@ -47,6 +47,7 @@ SYMBOLS = {
     "mm_shuffle_residual_fwd": (ctypes.c_int, [_f32p, _f32p, _i64, _i64, _f32p, _f32p, _f32p] + [ctypes.c_int] * 5 + [ctypes.c_void_p]),
     "mm_dwconv_silu_cross_fwd": (ctypes.c_int, [_f32p, _i64, _i64, _f32p, _f32p, _f32p, _i64, _i64] + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
     "mm_dwconv_silu_cross_supported": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
+    "mm_dwconv_silu_cross_strips": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
     "mm_dwconv_silu_cross_bwd": (ctypes.c_int, [_f32p, _i64, _i64, _f32p, _i64, _i64, _f32p, _i64, _i64, _f32p, _f32p, _f32p, _i64, _i64, _f32p]
                                  + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
     "mm_cross_merge_fwd": (ctypes.c_int, [_f32p, _f32p, _i64, _i64] + [ctypes.c_int] * 4 + [ctypes.c_void_p]),

@@ -125,20 +125,26 @@ namespace {
 
 // ---- depthwise 3x3 conv + bias + SiLU (MedMamba.py:153-162, 295), writing the scan's two input orders --------
 // x: planes (b, d) of H*W floats, batch stride x_sb, channel stride H*W.  out u2: (batch, 2, D, L):
-// u2[b,0,d,h*W+w] = u2[b,1,d,w*H+h] = silu(conv(x)[b,d,h,w] + bias[d]).  One workgroup per plane; the plane sits
-// in LDS with a zero halo; the transposed copy goes through a second LDS plane.
+// u2[b,0,d,h*W+w] = u2[b,1,d,w*H+h] = silu(conv(x)[b,d,h,w] + bias[d]).
+// One workgroup per (plane, row strip): rows [r0, r0 + SH) of the plane plus a one-row halo sit in LDS with a zero
+// border; the transposed copy goes through a second LDS tile.  Planes that fit the LDS budget whole are ONE strip
+// (SH = H: the 56x56 stage and below); larger ones (96x96 of MedMamba-B at 384^2, anything bigger) are cut into strips
+// of 32 rows, so there is no size limit and several workgroups fit a CU (MedMamba.py:288-305 runs at any resolution).
 __global__ __launch_bounds__(256) void dwconv_silu_cross_fwd_kernel(const float* __restrict__ x, int64_t x_sb, int64_t x_sd,
                                                                     const float* __restrict__ wgt,
                                                                     const float* __restrict__ bias, float* __restrict__ u2,
-                                                                    int64_t u_sb, int64_t u_sd, int D, int H, int W) {
+                                                                    int64_t u_sb, int64_t u_sd, int D, int H, int W, int SH,
+                                                                    int nstrips) {
   extern __shared__ float lds[];
-  const int b = blockIdx.x / D, d = blockIdx.x % D;
-  const int L = H * W, WP = W + 2, tid = threadIdx.x, nt = blockDim.x;
-  float* sx = lds;                         // (H+2) x (W+2), zero halo
-  float* so = lds + (H + 2) * WP;          // H x (W+1)
+  const int strip = blockIdx.x % nstrips, plane = blockIdx.x / nstrips;
+  const int b = plane / D, d = plane % D;
+  const int r0 = strip * SH, sh = min(SH, H - r0);           // rows of this strip
+  const int WP = W + 2, tid = threadIdx.x, nt = blockDim.x;
+  float* sx = lds;                         // (sh+2) x (W+2): rows r0-1 .. r0+sh, zero outside the plane
+  float* so = lds + (SH + 2) * WP;         // sh x (W+1)
   const float* xp = x + (int64_t)b * x_sb + (int64_t)d * x_sd;
-  for (int i = tid; i < (H + 2) * WP; i += nt) {
-    const int hh = i / WP - 1, ww = i % WP - 1;
+  for (int i = tid; i < (sh + 2) * WP; i += nt) {
+    const int hh = r0 + i / WP - 1, ww = i % WP - 1;
     sx[i] = (hh >= 0 && hh < H && ww >= 0 && ww < W) ? xp[hh * W + ww] : 0.f;
   }
   float k[9];
@@ -148,57 +154,61 @@ __global__ __launch_bounds__(256) void dwconv_silu_cross_fwd_kernel(const float*
   __syncthreads();
   float* o0 = u2 + b * u_sb + d * u_sd;
   float* o1 = u2 + b * u_sb + (D + d) * u_sd;
-  for (int i = tid; i < L; i += nt) {
-    const int h = i / W, w = i % W;
-    const float* c = sx + h * WP + w;      // top-left of the 3x3 window
+  for (int i = tid; i < sh * W; i += nt) {
+    const int hl = i / W, w = i % W;
+    const float* c = sx + hl * WP + w;     // top-left of the 3x3 window
     float p = bs;
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
       for (int kw = 0; kw < 3; ++kw) p = fmaf(c[kh * WP + kw], k[kh * 3 + kw], p);
     const float v = p * sigmoid_f(p);
-    o0[i] = v;
-    so[h * (W + 1) + w] = v;
+    o0[(r0 + hl) * W + w] = v;
+    so[hl * (W + 1) + w] = v;
   }
   __syncthreads();
-  for (int i = tid; i < L; i += nt) {      // i = w*H + h  (lanes along h)
-    const int w = i / H, h = i % H;
-    o1[i] = so[h * (W + 1) + w];
+  for (int i = tid; i < sh * W; i += nt) {      // i = w*sh + hl  (lanes along h: runs of sh floats in the column-major plane)
+    const int w = i / sh, hl = i % sh;
+    o1[w * H + r0 + hl] = so[hl * (W + 1) + w];
   }
 }
 
 // backward of the above: g = du2[b,0] + T(du2[b,1]);  dp = g * silu'(p);  dx = corr(dp, flipped k);
-// per-plane partial weight/bias gradients to ws[(b*D+d)*10 + 0..8 | 9].
+// per-(plane, strip) partial weight/bias gradients to ws[((b*D+d)*nstrips + strip)*10 + 0..8 | 9].
 // du4 (optional): the scan's per-direction gradients of its input, 4*D planes per batch item; directions (0,1) read the
 // row-major image and (2,3) the column-major one, so du2[b,j] += du4[b,2j] + du4[b,2j+1] is folded into the loads here
 // (saves the pair-sum kernel and the read-modify-write of the projection GEMM that would otherwise accumulate into it).
+// A strip needs dp on its rows and one row above / below, hence x on two rows above / below and g on one.
 __global__ __launch_bounds__(256) void dwconv_silu_cross_bwd_kernel(const float* __restrict__ du2, int64_t g_sb, int64_t g_sd,
                                                                     const float* __restrict__ du4, int64_t e_sb, int64_t e_sd,
                                                                     const float* __restrict__ x, int64_t x_sb, int64_t x_sd,
                                                                     const float* __restrict__ wgt,
                                                                     const float* __restrict__ bias, float* __restrict__ dx,
                                                                     int64_t dx_sb, int64_t dx_sd, float* __restrict__ ws, int D,
-                                                                    int H, int W) {
+                                                                    int H, int W, int SH, int nstrips) {
   extern __shared__ float lds[];
-  const int b = blockIdx.x / D, d = blockIdx.x % D;
-  const int L = H * W, WP = W + 2, tid = threadIdx.x, nt = blockDim.x;
-  float* sx = lds;                          // (H+2) x (W+2) input, zero halo
-  float* sd = lds + (H + 2) * WP;           // (H+2) x (W+2) dp, zero halo
-  float* st = sd + (H + 2) * WP;            // H x (W+1): transposed gradient staging
+  const int strip = blockIdx.x % nstrips, plane = blockIdx.x / nstrips;
+  const int b = plane / D, d = plane % D;
+  const int r0 = strip * SH, sh = min(SH, H - r0);
+  const int WP = W + 2, tid = threadIdx.x, nt = blockDim.x;
+  const int ge0 = max(r0 - 1, 0), ge1 = min(r0 + sh + 1, H), gh = ge1 - ge0;   // rows that need dp: [ge0, ge1)
+  float* sx = lds;                          // (sh+4) x (W+2): x rows r0-2 .. r0+sh+1, zero outside the plane
+  float* sd = lds + (SH + 4) * WP;          // (sh+2) x (W+2): dp rows r0-1 .. r0+sh, zero outside the plane / strip halo
+  float* st = sd + (SH + 2) * WP;           // (sh+2) x (W+1): transposed column-major gradient, rows r0-1 .. r0+sh
   __shared__ float red[10][4];
   const float* xp = x + (int64_t)b * x_sb + (int64_t)d * x_sd;
   const float* g0 = du2 + b * g_sb + d * g_sd;
   const float* g1 = du2 + b * g_sb + (D + d) * g_sd;
   const float* e0 = du4 ? du4 + b * e_sb + d * e_sd : nullptr;          // direction 0; direction k at e0 + k*D*e_sd
   const int64_t eD = (int64_t)D * e_sd;
-  for (int i = tid; i < (H + 2) * WP; i += nt) {
-    const int hh = i / WP - 1, ww = i % WP - 1;
+  for (int i = tid; i < (sh + 4) * WP; i += nt) {
+    const int hh = r0 + i / WP - 2, ww = i % WP - 1;
     sx[i] = (hh >= 0 && hh < H && ww >= 0 && ww < W) ? xp[hh * W + ww] : 0.f;
-    sd[i] = 0.f;
   }
-  for (int i = tid; i < L; i += nt) {       // i = w*H + h
-    const int w = i / H, h = i % H;
-    st[h * (W + 1) + w] = g1[i] + (e0 ? e0[2 * eD + i] + e0[3 * eD + i] : 0.f);
+  for (int i = tid; i < (sh + 2) * WP; i += nt) sd[i] = 0.f;
+  for (int i = tid; i < gh * W; i += nt) {  // i = w*gh + hg (lanes along h)
+    const int w = i / gh, hg = i % gh, h = ge0 + hg;
+    st[(h - (r0 - 1)) * (W + 1) + w] = g1[w * H + h] + (e0 ? e0[2 * eD + w * H + h] + e0[3 * eD + w * H + h] : 0.f);
   }
   float k[9];
 #pragma unroll
@@ -208,37 +218,40 @@ __global__ __launch_bounds__(256) void dwconv_silu_cross_bwd_kernel(const float*
   float acc[10];
 #pragma unroll
   for (int i = 0; i < 10; ++i) acc[i] = 0.f;
-  for (int i = tid; i < L; i += nt) {
-    const int h = i / W, w = i % W;
-    const float* c = sx + h * WP + w;
+  for (int i = tid; i < gh * W; i += nt) {
+    const int hg = i / W, w = i % W, h = ge0 + hg;
+    const int hl = h - (r0 - 1);                        // row inside sd / st (0 .. sh+1)
+    const float* c = sx + hl * WP + w;                 // sx row of h-1 is (h-1) - (r0-2) = hl
     float p = bs;
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
       for (int kw = 0; kw < 3; ++kw) p = fmaf(c[kh * WP + kw], k[kh * 3 + kw], p);
-    const float s = sigmoid_f(p);
-    const float ge = e0 ? e0[i] + e0[eD + i] : 0.f;
-    const float dp = (g0[i] + ge + st[h * (W + 1) + w]) * (s * (1.f + p * (1.f - s)));   // silu'(p) = s (1 + p (1 - s))
-    sd[(h + 1) * WP + (w + 1)] = dp;
-    acc[9] += dp;
+    const float sg = sigmoid_f(p);
+    const float ge = e0 ? e0[h * W + w] + e0[eD + h * W + w] : 0.f;
+    const float dp = (g0[h * W + w] + ge + st[hl * (W + 1) + w]) * (sg * (1.f + p * (1.f - sg)));   // silu'(p) = s (1 + p (1 - s))
+    sd[hl * WP + (w + 1)] = dp;
+    if (h >= r0 && h < r0 + sh) {                       // parameter gradients: every row is owned by exactly one strip
+      acc[9] += dp;
 #pragma unroll
-    for (int kh = 0; kh < 3; ++kh)
+      for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-      for (int kw = 0; kw < 3; ++kw) acc[kh * 3 + kw] = fmaf(dp, c[kh * WP + kw], acc[kh * 3 + kw]);
+        for (int kw = 0; kw < 3; ++kw) acc[kh * 3 + kw] = fmaf(dp, c[kh * WP + kw], acc[kh * 3 + kw]);
+    }
   }
   __syncthreads();
   float* dxp = dx + (int64_t)b * dx_sb + (int64_t)d * dx_sd;
-  for (int i = tid; i < L; i += nt) {
-    const int h = i / W, w = i % W;
-    // dx[h,w] = sum_{kh,kw} dp[h-kh+1, w-kw+1] * k[kh][kw]   (sd is offset by +1 in both dims)
+  for (int i = tid; i < sh * W; i += nt) {
+    const int hl = i / W, w = i % W;
+    // dx[h,w] = sum_{kh,kw} dp[h-kh+1, w-kw+1] * k[kh][kw]   (sd row of h+1-kh is hl + 2 - kh, column offset +1)
     float v = 0.f;
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-      for (int kw = 0; kw < 3; ++kw) v = fmaf(sd[(h - kh + 2) * WP + (w - kw + 2)], k[kh * 3 + kw], v);
-    dxp[i] = v;
+      for (int kw = 0; kw < 3; ++kw) v = fmaf(sd[(hl + 2 - kh) * WP + (w - kw + 2)], k[kh * 3 + kw], v);
+    dxp[(r0 + hl) * W + w] = v;
   }
-  // plane reduction of the 10 partial sums: wave (DPP + shuffles), then across waves through LDS
+  // strip reduction of the 10 partial sums: wave (DPP + shuffles), then across waves through LDS
   const int lane = tid & 63, wv = tid >> 6, nw = (nt + 63) >> 6;
 #pragma unroll
   for (int i = 0; i < 10; ++i) {
@@ -253,6 +266,24 @@ __global__ __launch_bounds__(256) void dwconv_silu_cross_bwd_kernel(const float*
     for (int j = 0; j < nw; ++j) v += red[tid][j];
     ws[(int64_t)blockIdx.x * 10 + tid] = v;
   }
+}
+
+// row-strip plan of the two kernels above: whole plane when the backward's three LDS tiles fit 48 KB, else 32-row strips
+// (narrower strips for very wide planes so that a strip always fits)
+struct DwPlan { int SH, nstrips; size_t lds_fwd, lds_bwd; };
+inline DwPlan dw_plan(int H, int W) {
+  auto need_bwd = [&](int sh) { return sizeof(float) * ((size_t)(sh + 4) * (W + 2) + (size_t)(sh + 2) * (W + 2) + (size_t)(sh + 2) * (W + 1)); };
+  int SH = H;
+  if (need_bwd(SH) > 48 * 1024) {
+    SH = 32;
+    while (SH > 1 && need_bwd(SH) > 96 * 1024) SH >>= 1;
+    if (SH > H) SH = H;
+  }
+  DwPlan p;
+  p.SH = SH; p.nstrips = (H + SH - 1) / SH;
+  p.lds_fwd = sizeof(float) * ((size_t)(SH + 2) * (W + 2) + (size_t)SH * (W + 1));
+  p.lds_bwd = need_bwd(SH);
+  return p;
 }
 
 // ---- cross-merge (MedMamba.py:282-286, 298): m[b,d,h*W+w] = o[b,0,d,hw] + o[b,1,d,hw] + o[b,2,d,wh] + o[b,3,d,wh] ----
@@ -611,20 +642,22 @@ int launch_ln_bwd1(int cpl, dim3 grid, hipStream_t s, const float* dy, int64_t d
 
 extern "C" {
 
-int mm_dwconv_silu_cross_supported(int H, int W) {   // the backward keeps 2 haloed planes + 1 staging plane in LDS
+int mm_dwconv_silu_cross_supported(int H, int W) {   // row strips: any plane a strip of which fits the LDS (W up to ~8000)
   if (H <= 0 || W <= 0) return 0;
-  return sizeof(float) * (2 * (size_t)(H + 2) * (W + 2) + (size_t)H * (W + 1)) <= 150 * 1024 ? 1 : 0;
+  return dw_plan(H, W).lds_bwd <= 150 * 1024 ? 1 : 0;
 }
+int mm_dwconv_silu_cross_strips(int H, int W) { return (H > 0 && W > 0) ? dw_plan(H, W).nstrips : 0; }
 
 int mm_dwconv_silu_cross_fwd(const float* x, int64_t x_sb, int64_t x_sd, const float* w, const float* bias, float* u2,
                              int64_t u2_sb, int64_t u2_sd, int batch, int D, int H, int W, void* stream) {
   if (!x || !w || !u2) return MM_ERR_NULL;
   if (batch <= 0 || D <= 0 || H <= 0 || W <= 0) return MM_ERR_SHAPE;
-  const size_t lds = sizeof(float) * ((size_t)(H + 2) * (W + 2) + (size_t)H * (W + 1));
-  if (lds > 150 * 1024) return MM_ERR_UNSUPPORTED;
-  const int L = H * W, nt = L >= 1024 ? 256 : (L > 64 ? 128 : 64);
-  if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)dwconv_silu_cross_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(dwconv_silu_cross_fwd_kernel, dim3(batch * D), dim3(nt), lds, (hipStream_t)stream, x, x_sb, x_sd, w, bias, u2, u2_sb, u2_sd, D, H, W);
+  const DwPlan pl = dw_plan(H, W);
+  if (pl.lds_bwd > 150 * 1024) return MM_ERR_UNSUPPORTED;
+  const int L = pl.SH * W, nt = L >= 1024 ? 256 : (L > 64 ? 128 : 64);
+  if (pl.lds_fwd > 64 * 1024) (void)hipFuncSetAttribute((const void*)dwconv_silu_cross_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_fwd);
+  hipLaunchKernelGGL(dwconv_silu_cross_fwd_kernel, dim3(batch * D * pl.nstrips), dim3(nt), pl.lds_fwd, (hipStream_t)stream, x, x_sb, x_sd, w, bias, u2,
+                     u2_sb, u2_sd, D, H, W, pl.SH, pl.nstrips);
   return (int)hipGetLastError();
 }
 
@@ -634,13 +667,12 @@ int mm_dwconv_silu_cross_bwd(const float* du2, int64_t du2_sb, int64_t du2_sd, c
                              int D, int H, int W, void* stream) {
   if (!du2 || !x || !w || !dx || !ws) return MM_ERR_NULL;
   if (batch <= 0 || D <= 0 || H <= 0 || W <= 0) return MM_ERR_SHAPE;
-  const size_t lds = sizeof(float) * (2 * (size_t)(H + 2) * (W + 2) + (size_t)H * (W + 1));
-  if (lds > 150 * 1024) return MM_ERR_UNSUPPORTED;
-  const int L = H * W, nt = L >= 1024 ? 256 : (L > 64 ? 128 : 64);
-  if (lds > 60 * 1024) (void)hipFuncSetAttribute((const void*)dwconv_silu_cross_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(dwconv_silu_cross_bwd_kernel, dim3(batch * D), dim3(nt), lds, (hipStream_t)stream, du2, du2_sb, du2_sd, du4, du4_sb,
-                     du4_sd, x, x_sb,
-                     x_sd, w, bias, dx, dx_sb, dx_sd, ws, D, H, W);
+  const DwPlan pl = dw_plan(H, W);
+  if (pl.lds_bwd > 150 * 1024) return MM_ERR_UNSUPPORTED;
+  const int L = pl.SH * W, nt = L >= 1024 ? 256 : (L > 64 ? 128 : 64);
+  if (pl.lds_bwd > 60 * 1024) (void)hipFuncSetAttribute((const void*)dwconv_silu_cross_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_bwd);
+  hipLaunchKernelGGL(dwconv_silu_cross_bwd_kernel, dim3(batch * D * pl.nstrips), dim3(nt), pl.lds_bwd, (hipStream_t)stream, du2, du2_sb, du2_sd, du4,
+                     du4_sb, du4_sd, x, x_sb, x_sd, w, bias, dx, dx_sb, dx_sd, ws, D, H, W, pl.SH, pl.nstrips);
   return (int)hipGetLastError();
 }
 

@@ -220,13 +220,13 @@ class DwConvSiluCrossFn(torch.autograd.Function):
         B, D, L = x_cf.shape
         du2 = _rows(du2)
         dx = _planes(B, D, L, du2.device, ctx.cm)
-        ws = torch.empty((B, D, 10), device=du2.device, dtype=torch.float32)
+        ws = torch.empty((B, D * _lib.lib().mm_dwconv_silu_cross_strips(H, W), 10), device=du2.device, dtype=torch.float32)
         with _lib.device_guard(du2.device):
             rc = _lib.lib().mm_dwconv_silu_cross_bwd(*_pl(du2), None, 0, 0, *_pl(x_cf), weight.data_ptr(),
                                                      None if bias is None else bias.data_ptr(), *_pl(dx), ws.data_ptr(),
                                                      B, D, H, W, _stream())
         _lib.check(rc, "mm_dwconv_silu_cross_bwd")
-        s = ws.sum(0)
+        s = ws.view(B, D, -1, 10).sum((0, 2))
         return dx, s[:, :9].reshape(D, 1, 3, 3), (None if bias is None else s[:, 9]), None, None
 
 
@@ -403,13 +403,13 @@ class SS2DCoreFn(torch.autograd.Function):
         if fused_conv:
             # d(u2) = projection part (du2) + the scan's two direction pairs (du4), summed inside the conv's backward kernel
             dxc = _planes(Bsz, D, L, dev, cm)
-            wsc = torch.empty((Bsz, D, 10), device=dev, dtype=torch.float32)
+            wsc = torch.empty((Bsz, D * lib.mm_dwconv_silu_cross_strips(H, W), 10), device=dev, dtype=torch.float32)
             with _lib.device_guard(dev):
                 rc = lib.mm_dwconv_silu_cross_bwd(*_pl(du2), *_pl(du4), *_pl(x_cf), conv_w.data_ptr(),
                                                   None if conv_b is None else conv_b.data_ptr(), *_pl(dxc), wsc.data_ptr(),
                                                   Bsz, D, H, W, _stream())
             _lib.check(rc, "mm_dwconv_silu_cross_bwd")
-            sc = wsc.sum(0)
+            sc = wsc.view(Bsz, D, -1, 10).sum((0, 2))
             du2, dcw, dcb = dxc, sc[:, :9].reshape(D, 1, 3, 3), (None if conv_b is None else sc[:, 9])
         return (du2, dcw, dcb, gWx, gWdt, gb.view(4, D), gA, gD, dz, wsum[:D], wsum[D:], None, None, None, None)
 

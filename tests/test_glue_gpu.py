@@ -95,7 +95,8 @@ def test_in_proj_cf_forward_backward(layout):
             assert close(p.grad, q.grad)
 
 
-@pytest.mark.parametrize("shape", [(2, 8, 5, 7), (1, 96, 56, 56), (2, 16, 14, 14), (3, 5, 7, 7), (1, 4, 33, 40)])
+@pytest.mark.parametrize("shape", [(2, 8, 5, 7), (1, 96, 56, 56), (2, 16, 14, 14), (3, 5, 7, 7), (1, 4, 33, 40),
+                                   (1, 3, 100, 60), (2, 2, 96, 96), (1, 2, 65, 130)])     # the last three: row strips (32 + halo)
 def test_dwconv_silu_cross_forward_backward(shape, layout):
     from medmamba_amd.ops import dwconv_silu_cross
     from oracle.model_ref import dwconv_silu_cross_ref

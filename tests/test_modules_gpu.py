@@ -320,14 +320,15 @@ def test_frozen_block_and_full_drop_rate(monkeypatch):
     assert seen[4] is not None and bool((seen[4] == 0).all()) and bool(torch.isfinite(seen[4]).all())
 
 
-def test_planes_beyond_the_fused_kernels_lds_budget():
-    """ADVICE r1 / VERDICT weak #9: a 120 x 120 feature map exceeds the LDS budget of the fused depthwise-conv kernels;
-    SS2D.forward_cf decides at forward time and routes to the generic conv + ss2d_core — forward and backward run and agree
-    with the module-by-module path (HIP scan operator)."""
+def test_large_planes_run_in_row_strips():
+    """ADVICE r1 / VERDICT weak #9: a 120 x 120 feature map (a 480^2 input) does not fit the LDS as a whole plane; the fused
+    depthwise-conv kernels cut it into 32-row strips with halos, so SS2D runs at any resolution like the reference
+    (MedMamba.py:288-305) — forward and backward agree with the module-by-module path (MIOpen conv + HIP scan operator)."""
     from medmamba_amd import _lib
     from medmamba_amd.modules import SS2D
-    assert _lib.lib().mm_dwconv_silu_cross_supported(56, 56) == 1
-    assert _lib.lib().mm_dwconv_silu_cross_supported(120, 120) == 0
+    lib = _lib.lib()
+    assert lib.mm_dwconv_silu_cross_strips(56, 56) == 1 and lib.mm_dwconv_silu_cross_strips(120, 120) == 4
+    assert lib.mm_dwconv_silu_cross_supported(120, 120) == 1 and lib.mm_dwconv_silu_cross_supported(8, 100000) == 0
     torch.manual_seed(4)
     m = SS2D(d_model=2).to(DEV)
     x = torch.randn(1, 120, 120, 2, device=DEV, requires_grad=True)
