@@ -140,6 +140,8 @@ def main():
     ap.add_argument("--res", type=int, default=224)
     ap.add_argument("--mode", default="train", choices=["train", "fwd"], help="train: fwd + CE + bwd + AdamW (config 3/4/5); "
                     "fwd: eval-mode forward under no_grad (config 2)")
+    ap.add_argument("--graph", action="store_true", help="--mode fwd only: replay the forward from one hipGraph "
+                    "(medmamba_amd.graphs.GraphedInference) instead of ~550 eager launches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse)")
     ap.add_argument("--no-alone-pass", action="store_true", help="skip the 3 untimed steps that re-measure the scan kernels "
@@ -196,9 +198,15 @@ def main():
         opt.step()
         return loss.detach()            # do not keep the autograd graph (and its AccumulateGrad nodes) alive across steps
 
+    graphed = None
+    if args.graph:
+        assert args.mode == "fwd" and world == 1, "--graph is for the single-GPU inference forward"
+        from medmamba_amd.graphs import GraphedInference
+        graphed = GraphedInference(net, images)
+
     def fwd_step():
         with torch.no_grad():
-            return loss_fn(model(images), labels)
+            return loss_fn(graphed(images) if graphed is not None else model(images), labels)
 
     step = train_step if args.mode == "train" else fwd_step
 
@@ -266,7 +274,8 @@ def main():
             return r
 
         what = "fwd+bwd" if args.mode == "train" else "fwd"
-        work = "training step (fwd + CE loss + bwd + AdamW)" if args.mode == "train" else "inference forward (eval, no_grad) + CE loss"
+        work = "training step (fwd + CE loss + bwd + AdamW)" if args.mode == "train" else \
+            ("inference forward (eval, no_grad" + (", replayed from one hipGraph" if args.graph else "") + ") + CE loss")
         out = {
             "metric": f"images/sec {what} MedMamba-{args.size} {args.res}^2", "value": round(args.batch * world * args.steps / dt, 2),
             "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

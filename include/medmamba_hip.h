@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MM_ABI_VERSION 14
+#define MM_ABI_VERSION 15
 
 enum mm_status {
   MM_OK = 0,
@@ -105,6 +105,16 @@ typedef struct mm_scan_args {
    * du and ddelta rows at base + b*dud_sb + d*o_sd (one channel stride for the three).  Lets them live in channel-major
    * planes (channel, batch, L) where the projections around the scan are single large GEMMs. */
   int64_t dout_sb, dud_sb, o_sd;
+  /* forward, optional: the dt projection of SS2D (MedMamba.py:262: dts = einsum(dts, dt_projs_weight)) fused into the scan.
+   * dt_w != NULL: `delta` is not read (may be NULL); instead delta[b,d,t] = sum_r dt_w[d*dt_rank + r] * dts[b, g(d), r, t] with
+   * dt_w (dim, dt_rank) contiguous and dts (batch, G, dt_rank, L) with element strides (dts_sb, dts_sg, dts_sn, 1) — the first
+   * dt_rank rows of x_dbl (MedMamba.py:261).  dt_rank <= mm_scan_dt_max(); needs L % 4 == 0, 16-B aligned rows and
+   * delta_softplus; anything else returns MM_ERR_UNSUPPORTED and the caller materialises delta with a GEMM.  The backward
+   * entry point ignores these fields (it needs delta as a tensor). */
+  const float* dt_w;
+  const float* dts;
+  int64_t dts_sb, dts_sg, dts_sn;
+  int32_t dt_rank;
 } mm_scan_args;
 
 /* replaces selective_scan_cuda.fwd behind selective_scan_fn (MedMamba.py:273-279) */
@@ -113,6 +123,8 @@ int mm_scan_fwd(const mm_scan_args* args, void* stream);
 int mm_scan_bwd(const mm_scan_args* args, void* stream);
 /* checkpoint interval (steps) of x_chk */
 int mm_scan_chunk(void);
+/* largest dt_rank mm_scan_fwd fuses (mm_scan_args.dt_w) */
+int mm_scan_dt_max(void);
 
 /* Block glue of SS_Conv_SSM.forward (MedMamba.py:354-357 + channel_shuffle :308-320), one pass over HBM:
  *   out[b,p,2i] = left[b,i,p] + inp[b,p,2i] ;  out[b,p,2i+1] = ssm[b,p,i] + inp[b,p,2i+1]

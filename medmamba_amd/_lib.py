@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "lib", "libmedmamba_hip.so")
 
-ABI_VERSION = 14        # == MM_ABI_VERSION of include/medmamba_hip.h (checked when the library is loaded)
+ABI_VERSION = 15        # == MM_ABI_VERSION of include/medmamba_hip.h (checked when the library is loaded)
 _f32p = ctypes.c_void_p
 _i64 = ctypes.c_int64
 
@@ -34,6 +34,8 @@ class ScanArgs(ctypes.Structure):
         ("dB_sb", ctypes.c_int64), ("dB_sg", ctypes.c_int64), ("dB_sn", ctypes.c_int64),
         ("dC_sb", ctypes.c_int64), ("dC_sg", ctypes.c_int64), ("dC_sn", ctypes.c_int64),
         ("dout_sb", ctypes.c_int64), ("dud_sb", ctypes.c_int64), ("o_sd", ctypes.c_int64),
+        ("dt_w", _f32p), ("dts", _f32p), ("dts_sb", ctypes.c_int64), ("dts_sg", ctypes.c_int64), ("dts_sn", ctypes.c_int64),
+        ("dt_rank", ctypes.c_int32),
     ]
 
 
@@ -41,6 +43,7 @@ class ScanArgs(ctypes.Structure):
 SYMBOLS = {
     "mm_abi_version": (ctypes.c_int, []),
     "mm_scan_chunk": (ctypes.c_int, []),
+    "mm_scan_dt_max": (ctypes.c_int, []),
     "mm_status_string": (ctypes.c_char_p, [ctypes.c_int]),
     "mm_scan_fwd": (ctypes.c_int, [ctypes.POINTER(ScanArgs), ctypes.c_void_p]),
     "mm_scan_bwd": (ctypes.c_int, [ctypes.POINTER(ScanArgs), ctypes.c_void_p]),

@@ -16,14 +16,14 @@ int check_common(const mm_scan_args* a) {
   if (a->batch <= 0 || a->dim <= 0 || a->L <= 0 || a->N <= 0 || a->G <= 0) return MM_ERR_SHAPE;
   if (a->dim % a->G != 0) return MM_ERR_SHAPE;
   if (a->N != mm::kNState) return MM_ERR_UNSUPPORTED;   // d_state = 16 on every MedMamba path (MedMamba.py:329,457)
-  if (!a->u || !a->delta || !a->A || !a->B || !a->C) return MM_ERR_NULL;
+  if (!a->u || (!a->delta && !a->dt_w) || !a->A || !a->B || !a->C) return MM_ERR_NULL;
   if (a->u_groups < 0) return MM_ERR_SHAPE;
   if (a->u_groups > 0 && a->u_groups < a->G) {
     if (a->G > 8) return MM_ERR_SHAPE;
     for (int g = 0; g < a->G; ++g)
       if ((int)((a->u_map >> (4 * g)) & 15) >= a->u_groups) return MM_ERR_SHAPE;
   }
-  if (!al4(a->u) || !al4(a->delta) || !al4(a->A) || !al4(a->B) || !al4(a->C)) return MM_ERR_ALIGN;
+  if (!al4(a->u) || (a->delta && !al4(a->delta)) || !al4(a->A) || !al4(a->B) || !al4(a->C)) return MM_ERR_ALIGN;
   return MM_OK;
 }
 }  // namespace
@@ -32,6 +32,7 @@ extern "C" {
 
 int mm_abi_version(void) { return MM_ABI_VERSION; }
 int mm_scan_chunk(void) { return mm::kChunk; }
+int mm_scan_dt_max(void) { return 8; }
 
 const char* mm_status_string(int s) {
   switch (s) {
@@ -55,7 +56,7 @@ int mm_scan_fwd(const mm_scan_args* a, void* stream) {
 int mm_scan_bwd(const mm_scan_args* a, void* stream) {
   int rc = check_common(a);
   if (rc) return rc;
-  if (!a->dout || !a->du || !a->ddelta || !a->dA || !a->dB || !a->dC) return MM_ERR_NULL;
+  if (!a->delta || !a->dout || !a->du || !a->ddelta || !a->dA || !a->dB || !a->dC) return MM_ERR_NULL;
   if (a->D && !a->dD) return MM_ERR_NULL;
   if (a->delta_bias && !a->ddelta_bias) return MM_ERR_NULL;
   if (!a->x_chk) return MM_ERR_WORKSPACE;

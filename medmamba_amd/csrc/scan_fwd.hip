@@ -47,6 +47,11 @@ struct FwdParams {
   unsigned u_map, rev_mask; // block of group g = (u_map >> 4g) & 15; bit g of rev_mask: group g runs backwards
   int ntiles, nchk;
   int nwaves_total;
+  // fused dt projection (MedMamba.py:262; inference): delta[d,t] = sum_r dtw[d,r] * dts[b,g,r,t] computed while staging
+  const float* __restrict__ dtw;   // (dim, R) in this kernel's direction order, or nullptr (then `delta` is read)
+  const float* __restrict__ dts;   // (batch, G, R, L) rows with strides (dts_sb, dts_sg, dts_sn, 1)
+  int64_t dts_sb, dts_sg, dts_sn;
+  int R;
   int dbg;   // timing-only ablation bits (bench diagnostics; results are wrong when set): 1 no y store, 2 no recurrence
 };
 
@@ -59,7 +64,9 @@ __device__ __forceinline__ float f4get(const float4& v, int i) {
 //       loaded where they are consumed instead of one tile ahead, the recurrence uses one operand set, and the
 //       tile's stores are issued as soon as they exist.  Without LEAN (few, long wavefronts) everything is
 //       software-pipelined in registers.
-template <int NS, bool VEC, bool SP, bool LEAN>
+// DT: the dt projection (rank R <= kDtMax) is fused into the staging phase: no (batch, K*D, L) delta tensor is read.
+constexpr int kDtMax = 8;
+template <int NS, bool VEC, bool SP, bool LEAN, bool DT = false>
 __global__ __launch_bounds__(256) void scan_fwd_kernel(const FwdParams p) {
   constexpr int SG = kNState / NS;   // lanes per channel
   constexpr int CH = kWave / SG;     // channels per wave (= 4*NS)
@@ -120,9 +127,12 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(const FwdParams p) {
   const rsrc_t ro = make_rsrc(p.out + ((int64_t)b * p.dim + d0) * p.L, (int64_t)nrw * p.L * 4);
   const rsrc_t rB = make_rsrc(p.B + b * p.B_sb + grp * p.B_sg, ((int64_t)(kNState - 1) * p.B_sn + p.L) * 4);
   const rsrc_t rC = make_rsrc(p.C + b * p.C_sb + grp * p.C_sg, ((int64_t)(kNState - 1) * p.C_sn + p.L) * 4);
+  const rsrc_t rT = make_rsrc(DT ? p.dts + b * p.dts_sb + grp * p.dts_sg : nullptr, DT ? ((int64_t)(p.R - 1) * p.dts_sn + p.L) * 4 : 0);
+  const int tstep = DT ? (int)p.dts_sn * 4 : 0;
   float Dv[NLD], bv[NLD];
   bool rvalid[NLD];
   int uoff[NLD], doff[NLD], ooff[NLD];
+  float wdt[DT ? NLD : 1][DT ? kDtMax : 1];        // this lane's rows of the dt projection weight
 #pragma unroll
   for (int i = 0; i < NLD; ++i) {
     rvalid[i] = hc0 + RPI * i < p.H;
@@ -132,6 +142,10 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(const FwdParams p) {
     uoff[i] = (int)((r + RPI * i) * p.u_sd) * 4;
     doff[i] = (int)((r + RPI * i) * p.d_sd) * 4;
     ooff[i] = ((r + RPI * i) * p.L) * 4;
+    if constexpr (DT) {
+#pragma unroll
+      for (int k = 0; k < kDtMax; ++k) wdt[i][k] = k < p.R ? p.dtw[(int64_t)dd * p.R + k] : 0.f;
+    }
   }
   // B/C staging: NBC float4 per lane per tile: k -> (which = k / (NBC/2), n = (k % (NBC/2)) * RPI + r, column q)
   int bcoff[NBC];
@@ -141,13 +155,17 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(const FwdParams p) {
     bcoff[k] = (int)(n * ((k >= NBC / 2) ? p.C_sn : p.B_sn)) * 4;
   }
 
-  float4 pu[NLD], pd[NLD], pbc[NPBC];
+  float4 pu[NLD], pd[DT ? 1 : NLD], pbc[NPBC], pdt[DT ? kDtMax : 1];
   auto issue_loads = [&](int t0) {
     const int t = t0 + 4 * q;
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
       pu[i] = load_quad<VEC, VEC>(ru, uoff[i], t, p.L, rev, rvalid[i]);
-      pd[i] = load_quad<VEC, VEC>(rd, doff[i], t, p.L, rev, rvalid[i]);
+      if constexpr (!DT) pd[i] = load_quad<VEC, VEC>(rd, doff[i], t, p.L, rev, rvalid[i]);
+    }
+    if constexpr (DT) {   // the R rows of dts are shared by every channel of the direction (L1 / L2 after the first wave)
+#pragma unroll
+      for (int k = 0; k < kDtMax; ++k) pdt[k] = load_quad<VEC, VEC>(rT, k * tstep, t, p.L, rev, k < p.R);
     }
     if constexpr (!LEAN) {
 #pragma unroll
@@ -177,9 +195,20 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(const FwdParams p) {
     for (int i = 0; i < NLD; ++i) {
       const int t = t0 + 4 * q;
       float4 dl, du;
+      float4 dr;
+      if constexpr (DT) {
+        dr = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < kDtMax; ++k) {      // rows k >= R were loaded as zeros with zero weights
+          dr.x = fmaf(wdt[i][k], pdt[k].x, dr.x); dr.y = fmaf(wdt[i][k], pdt[k].y, dr.y);
+          dr.z = fmaf(wdt[i][k], pdt[k].z, dr.z); dr.w = fmaf(wdt[i][k], pdt[k].w, dr.w);
+        }
+      } else {
+        dr = pd[i];
+      }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float raw = f4get(pd[i], e) + bv[i];
+        const float raw = f4get(dr, e) + bv[i];
         float v = SP ? softplus_f(raw) : raw;
         // identity step outside the sequence / channel range (vector path: L % 4 == 0, a quad is inside or outside as a whole)
         v = (rvalid[i] && (VEC ? t < p.L : t + e < p.L)) ? v : 0.f;
@@ -293,21 +322,22 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(const FwdParams p) {
   if constexpr (!LEAN) store_tile((p.ntiles - 1) * kTile);
 }
 
-template <int NS, bool VEC, bool SP, bool LEAN>
+template <int NS, bool VEC, bool SP, bool LEAN, bool DT = false>
 int launch(const FwdParams& p, int nblocks, int wpb, hipStream_t stream) {
   constexpr int CH = 4 * NS;
   constexpr int TS = fwd_tile(NS, LEAN) + 4;
   const size_t lds = sizeof(float) * (size_t)wpb * (2 * CH * TS + 2 * kNState * TS);
   if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute((const void*)scan_fwd_kernel<NS, VEC, SP, LEAN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)scan_fwd_kernel<NS, VEC, SP, LEAN, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   FwdParams q = p;
   q.ntiles = (p.L + fwd_tile(NS, LEAN) - 1) / fwd_tile(NS, LEAN);
-  hipLaunchKernelGGL((scan_fwd_kernel<NS, VEC, SP, LEAN>), dim3(nblocks), dim3(wpb * 64), lds, stream, q);
+  hipLaunchKernelGGL((scan_fwd_kernel<NS, VEC, SP, LEAN, DT>), dim3(nblocks), dim3(wpb * 64), lds, stream, q);
   return (int)hipGetLastError();
 }
 
 template <int NS, bool LEAN>
 int launch_l(const FwdParams& p, int nblocks, int wpb, bool vec, bool sp, hipStream_t stream) {
+  if (p.dtw != nullptr) return launch<NS, true, true, LEAN, true>(p, nblocks, wpb, stream);   // (checked by the caller: vec && sp)
   if (vec) return sp ? launch<NS, true, true, LEAN>(p, nblocks, wpb, stream) : launch<NS, true, false, LEAN>(p, nblocks, wpb, stream);
   return sp ? launch<NS, false, true, LEAN>(p, nblocks, wpb, stream) : launch<NS, false, false, LEAN>(p, nblocks, wpb, stream);
 }
@@ -367,6 +397,7 @@ int scan_fwd_launch(const mm_scan_args* a, hipStream_t stream) {
   if (span >= 0x7ffffff0ll || (int64_t)kNState * (a->B_sn > a->C_sn ? a->B_sn : a->C_sn) * 4 >= 0x7ffffff0ll)
     return MM_ERR_UNSUPPORTED;
   p.nwaves_total = a->batch * a->G * p.wpg;
+  p.dtw = nullptr; p.dts = nullptr; p.dts_sb = p.dts_sg = p.dts_sn = 0; p.R = 0;
   int nblocks = (p.nwaves_total + wpb - 1) / wpb;
   nblocks = (nblocks + 7) & ~7;             // multiple of 8 so the XCD remap is a bijection; surplus waves exit
 
@@ -375,6 +406,12 @@ int scan_fwd_launch(const mm_scan_args* a, hipStream_t stream) {
                    a->delta_sd % 4 == 0 && a->B_sb % 4 == 0 && a->B_sg % 4 == 0 && a->B_sn % 4 == 0 &&
                    a->C_sb % 4 == 0 && a->C_sg % 4 == 0 && a->C_sn % 4 == 0;
   const bool sp = a->delta_softplus != 0;
+  if (a->dt_w != nullptr) {     // fused dt projection: vector path with softplus only (the SS2D call: MedMamba.py:262, 273-279)
+    if (!a->dts || a->dt_rank <= 0 || a->dt_rank > kDtMax || !vec || !sp || !aligned16(a->dts) || a->dts_sb % 4 || a->dts_sg % 4 ||
+        a->dts_sn % 4 || (int64_t)kDtMax * a->dts_sn * 4 >= 0x7ffffff0ll)
+      return MM_ERR_UNSUPPORTED;
+    p.dtw = a->dt_w; p.dts = a->dts; p.dts_sb = a->dts_sb; p.dts_sg = a->dts_sg; p.dts_sn = a->dts_sn; p.R = a->dt_rank;
+  }
   // variant bit 24: force LEAN on, bit 25: force LEAN off; default: lean when the grid offers >= 3 waves per SIMD
   // (measured, S/Bz=64: LEAN wins for NS=4 at >= 3072 waves: 0.19 vs 0.21 ms stage 2, 0.088 vs 0.105 ms stage 3;
   //  it loses for NS=2 on the long stage-1 sequences: 0.49 vs 0.43 ms)

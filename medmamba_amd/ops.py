@@ -24,6 +24,7 @@ def _need_hip(*ts):
 #                good split-K for K = B*L ~ 2e5), hence channel-major only for short sequences.
 # Every plane kernel takes (batch stride, channel stride), so both layouts run the same code.
 _LAYOUT = os.environ.get("MM_LAYOUT", "auto")          # "auto" | "bm" | "cm" (tests force both)
+_FUSE_DT = os.environ.get("MM_FUSE_DT", "1") == "1"     # inference: dt projection inside the scan kernel (MM_FUSE_DT=0: always a GEMM)
 
 
 def channel_major(B, L):
@@ -267,7 +268,7 @@ class SS2DCoreFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, u2, conv_w, conv_b, x_proj_w, dt_w, dt_b, A_logs, Ds, z_cf, ln_w, ln_b, H, W, eps, prescan_event=None):
-        from .selective_scan_interface import _CROSS_SHARED, _launch_fwd
+        from .selective_scan_interface import _CROSS_SHARED, _launch_fwd, dt_fusable
         lib = _lib.lib()
         dev = u2.device
         L = u2.shape[2]
@@ -295,22 +296,30 @@ class SS2DCoreFn(torch.autograd.Function):
             rc = lib.mm_ss2d_pack_fwd(*[t.data_ptr() for t in srcs], P.data_ptr(), D, C, R, N, _stream())
         _lib.check(rc, "mm_ss2d_pack_fwd")
         Wx, Wdt, A, Dp, dbias = SS2DCoreFn._segments(P, D, C, R, N)
+        need_grad = any(ctx.needs_input_grad)
         if cm:
             u2m = _cm2d(_rows(u2))                                                             # (2D, Q)
             u2 = u2m.view(2 * D, Bsz, L).permute(1, 0, 2)
             x_dbl = torch.bmm(Wx.view(2, 2 * C, D), u2m.view(2, D, Q)).view(4, C, Q)              # :259
-            delta = torch.bmm(Wdt, x_dbl[:, :R]).view(4 * D, Bsz, L).permute(1, 0, 2)            # :262  (B, 4D, L) view
             xb = x_dbl.view(4, C, Bsz, L).permute(2, 0, 1, 3)                                   # (B, 4, C, L) view
         else:
             u2 = u2.float().contiguous()
             x_dbl = torch.matmul(Wx.view(1, 2, 2 * C, D), u2.view(Bsz, 2, D, L)).view(Bsz, 4, C, L)
-            delta = torch.matmul(Wdt.unsqueeze(0), x_dbl[:, :, :R]).view(Bsz, 4 * D, L)
             xb = x_dbl
-        need_grad = any(ctx.needs_input_grad)
+        # inference (nothing to differentiate) with a small dt rank: the dt projection (:262) runs inside the scan's staging
+        # phase — no (B, 4D, L) delta tensor is written or read, one GEMM less; training keeps the GEMM (the backward kernel
+        # consumes delta as a tensor)
+        fuse_dt = _FUSE_DT and not need_grad and dt_fusable(R, L, xb[:, :, :R])
+        if fuse_dt:
+            delta = None
+        elif cm:
+            delta = torch.bmm(Wdt, x_dbl[:, :R]).view(4 * D, Bsz, L).permute(1, 0, 2)            # :262  (B, 4D, L) view
+        else:
+            delta = torch.matmul(Wdt.unsqueeze(0), x_dbl[:, :, :R]).view(Bsz, 4 * D, L)
         if prescan_event is not None:
             prescan_event.record()          # the projections are queued; what follows is the (latency-bound) scan
         out4, x_chk = _launch_fwd(u2, delta, A, xb[:, :, R:R + N], xb[:, :, R + N:], Dp, dbias, True, need_grad, 0,
-                                  _CROSS_SHARED)
+                                  _CROSS_SHARED, dt=(xb[:, :, :R], Wdt.reshape(4 * D, R)) if fuse_dt else None)
         z_cf = _rows(z_cf)
         ln_w, ln_b = ln_w.float().contiguous(), ln_b.float().contiguous()
         m = _planes(Bsz, D, L, dev, cm)

@@ -100,20 +100,31 @@ def _f32_rows(t):
 
 
 def _fill_common(a, u, delta, A, B, C, D, delta_bias, delta_softplus):
-    batch, dim, L = delta.shape
+    batch, L = u.shape[0], u.shape[2]
+    dim = A.shape[0]
     a.batch, a.dim, a.L, a.N, a.G = batch, dim, L, A.shape[1], B.shape[1]
     a.delta_softplus = int(bool(delta_softplus))
-    a.u, a.delta, a.A, a.B, a.C = u.data_ptr(), delta.data_ptr(), A.data_ptr(), B.data_ptr(), C.data_ptr()
+    a.u, a.delta, a.A, a.B, a.C = u.data_ptr(), _ptr(delta), A.data_ptr(), B.data_ptr(), C.data_ptr()
     a.D, a.delta_bias = _ptr(D), _ptr(delta_bias)
     a.u_sb, a.u_sd = u.stride(0), u.stride(1)
-    a.delta_sb, a.delta_sd = delta.stride(0), delta.stride(1)
+    if delta is not None:
+        a.delta_sb, a.delta_sd = delta.stride(0), delta.stride(1)
     a.B_sb, a.B_sg, a.B_sn = B.stride(0), B.stride(1), B.stride(2)
     a.C_sb, a.C_sg, a.C_sn = C.stride(0), C.stride(1), C.stride(2)
 
 
-def _launch_fwd(u, delta, A, B, C, D, delta_bias, delta_softplus, want_chk, variant=0, shared=(0, 0, 0)):
-    """mm_scan_fwd on torch's current stream. Returns (out (batch, G*H, L), x_chk or None)."""
-    batch, dim, L = delta.shape
+def dt_fusable(R, L, dts):
+    """True if mm_scan_fwd can compute delta = dt_w @ dts itself (mm_scan_args.dt_w): rank within the kernel's limit,
+    vector path (L % 4 == 0, 16-B aligned rows with strides that are multiples of 4 elements)."""
+    return (0 < R <= _lib.lib().mm_scan_dt_max() and L % 4 == 0 and dts.data_ptr() % 16 == 0 and dts.stride(3) == 1
+            and all(st % 4 == 0 for st in dts.stride()[:3]))
+
+
+def _launch_fwd(u, delta, A, B, C, D, delta_bias, delta_softplus, want_chk, variant=0, shared=(0, 0, 0), dt=None):
+    """mm_scan_fwd on torch's current stream. Returns (out (batch, G*H, L), x_chk or None).
+    dt = (dts (batch, G, R, L) view, dt_w (dim, R) contiguous): the dt projection is fused into the kernel and `delta` is None."""
+    batch, L = u.shape[0], u.shape[2]
+    dim = A.shape[0]
     out = torch.empty((batch, dim, L), device=u.device, dtype=torch.float32)
     x_chk = None
     if want_chk:
@@ -123,6 +134,11 @@ def _launch_fwd(u, delta, A, B, C, D, delta_bias, delta_softplus, want_chk, vari
     _fill_common(a, u, delta, A, B, C, D, delta_bias, delta_softplus)
     a.out, a.x_chk, a.variant = out.data_ptr(), _ptr(x_chk), int(variant) or _FWD_VARIANT
     a.u_groups, a.u_map, a.rev_mask = shared
+    if dt is not None:
+        dts, dt_w = dt
+        assert delta is None and dt_w.is_contiguous() and dt_w.shape[0] == dim and dts.shape == (batch, B.shape[1], dt_w.shape[1], L)
+        a.dt_w, a.dts, a.dt_rank = dt_w.data_ptr(), dts.data_ptr(), dt_w.shape[1]
+        a.dts_sb, a.dts_sg, a.dts_sn = dts.stride(0), dts.stride(1), dts.stride(2)
     with _lib.device_guard(u.device):
         t0 = KERNEL_TIMER.start()
         rc = _lib.lib().mm_scan_fwd(a, _lib.raw_stream())

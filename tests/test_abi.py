@@ -33,9 +33,18 @@ def test_library_exports_every_declared_symbol():
     assert b"unsupported" in _lib.lib().mm_status_string(-3)
 
 
-def test_struct_layout_matches_header():
-    # 6 int32 + 9 pointers + 10 int64 + 8 pointers + 4 int32 + 9 int64 (LP64)
-    assert ctypes.sizeof(_lib.ScanArgs) == 6 * 4 + 9 * 8 + 10 * 8 + 8 * 8 + 4 * 4 + 9 * 8
+def test_struct_layout_matches_header(tmp_path):
+    """sizeof / offsetof of mm_scan_args as gcc sees include/medmamba_hip.h == the ctypes mirror, field by field."""
+    import subprocess
+    names = [f[0] for f in _lib.ScanArgs._fields_]
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "medmamba_hip.h"\nint main(void){printf("%zu", sizeof(mm_scan_args));'
+                   + "".join(f'printf(" %zu", offsetof(mm_scan_args, {n}));' for n in names) + 'return 0;}\n')
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    assert got[0] == ctypes.sizeof(_lib.ScanArgs)
+    assert got[1:] == [getattr(_lib.ScanArgs, n).offset for n in names]
 
 
 def test_bad_arguments_are_rejected_without_launch():

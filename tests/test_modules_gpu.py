@@ -407,3 +407,22 @@ def test_eval_path_with_folded_batchnorm(monkeypatch):
     with torch.no_grad():
         _close(net(torch.from_numpy(fxm["x"]).to(DEV)), fxm["logits_eval"], 1e-4, "tiny VSSM logits, folded")
     assert len(calls) > 2
+
+
+def test_graphed_inference_matches_eager():
+    """medmamba_amd.graphs.GraphedInference: the eval forward recorded into one hipGraph (library kernels through the C ABI,
+    GEMMs, MIOpen convolutions, both streams) replays to the same logits as eager execution, also for new input values."""
+    from medmamba_amd import modules
+    from medmamba_amd.graphs import GraphedInference
+    torch.manual_seed(9)
+    net = modules.VSSM(num_classes=4, depths=[1, 1, 2, 1], dims=[16, 32, 64, 128]).to(DEV).eval()
+    x0 = torch.randn(4, 3, 64, 64, device=DEV)
+    g = GraphedInference(net, x0)
+    for seed in (1, 2):
+        x = torch.randn(4, 3, 64, 64, device=DEV, generator=torch.Generator(device=DEV).manual_seed(seed))
+        with torch.no_grad():
+            want = net(x)
+        got = g(x).clone()
+        assert float((got - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max()))
+    with pytest.raises(RuntimeError):
+        g(torch.randn(2, 3, 64, 64, device=DEV))
