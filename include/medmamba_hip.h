@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MM_ABI_VERSION 15
+#define MM_ABI_VERSION 16
 
 enum mm_status {
   MM_OK = 0,
@@ -218,6 +218,18 @@ int mm_patch_merge_ln_fwd(const float* x, const float* gamma, const float* beta,
                           int batch, int H, int W, int C, void* stream);
 int mm_patch_merge_ln_bwd(const float* dy, const float* x, const float* gamma, const float* mu, const float* rstd, float* dinp,
                           float* ws, int batch, int H, int W, int C, void* stream);
+
+/* Training-mode BatchNorm2d of the conv branch (MedMamba.py:338, 340, 343) with the nn.ReLU that follows two of them (:341,
+ * :344) folded in.  x, y, dy, dx: contiguous NCHW (batch, C, HW).  Semantics of torch.nn.BatchNorm2d in training mode: batch
+ * statistics (biased variance) for the normalisation; running_mean / running_var (either may be NULL) updated in place with
+ * `momentum` and the unbiased variance.  mean / rstd (C): saved batch statistics for the backward.
+ * ws: scratch of 3 * C * mm_bn_splits(batch, C, HW) floats (partial statistics; need not be initialised).
+ * relu != 0: y = max(0, bn(x)); the backward masks dy where bn(x) <= 0 (recomputed from x, y is not needed). */
+int mm_bn_splits(int batch, int C, int HW);
+int mm_bn_relu_fwd(const float* x, const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                   float* running_var, float* y, float* mean, float* rstd, float* ws, int relu, int batch, int C, int HW, void* stream);
+int mm_bn_relu_bwd(const float* dy, const float* x, const float* gamma, const float* beta, const float* mean, const float* rstd,
+                   float* dx, float* dgamma, float* dbeta, float* ws, int relu, int batch, int C, int HW, void* stream);
 
 /* SS2D parameters (MedMamba.py:150-175) -> one buffer in kernel direction order, A = -exp(A_logs) (MedMamba.py:271):
  *   x_proj_w (4, C, D), dt_w (4, D, R), dt_b (4, D), A_logs (4*D, N), Ds (4*D) in the reference's direction order

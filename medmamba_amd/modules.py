@@ -25,7 +25,8 @@ import torch.nn.functional as F
 import torch.utils.checkpoint as checkpoint
 
 from . import _lib
-from .ops import (PointwiseConvFn, block_split, block_split_infer, conv2d_bias, patch_merge_ln, patch_merge_ln_supported, dwconv_silu_cross, in_proj_cf, out_proj_cf, shuffle_residual,
+from .ops import (PointwiseConvFn, block_split, block_split_infer, bn_relu_train, conv2d_bias, patch_merge_ln,
+                  patch_merge_ln_supported, dwconv_silu_cross, in_proj_cf, out_proj_cf, shuffle_residual,
                   ss2d_conv_core, ss2d_core)
 from .selective_scan_interface import CROSS_SCAN_K_OF_G, cross_scan_fn, selective_scan_fn
 
@@ -33,6 +34,10 @@ trunc_normal_ = nn.init.trunc_normal_   # timm.layers.trunc_normal_ == torch.nn.
 
 _TWO_STREAMS = __import__("os").environ.get("MM_TWO_STREAMS", "1") == "1"   # MM_TWO_STREAMS=0: single-stream blocks
 _FOLD_BN = __import__("os").environ.get("MM_FOLD_BN", "1") == "1"         # MM_FOLD_BN=0: eval() keeps the BatchNorm launches
+# MM_GRAPH_CONV=1 (experimental): the conv branch of every block is replayed from hipGraphs in training (about 30 of a block's
+# 80 launches become 2); the SS2D branch stays eager.  Off by default: measured in DESIGN.md §4.5.
+_GRAPH_CONV = __import__("os").environ.get("MM_GRAPH_CONV", "0") == "1"
+_OWN_BN = __import__("os").environ.get("MM_OWN_BN", "1") == "1"         # MM_OWN_BN=0: training-mode BatchNorm / ReLU through MIOpen / ATen
 _SIDE_STREAMS = {}
 # images with at least this many positions start the side stream when the scan kernel is queued (see SS_Conv_SSM.forward)
 _LATE_SIDE_MIN_L = int(__import__("os").environ.get("MM_LATE_SIDE_MIN_L", "2048"))
@@ -60,12 +65,34 @@ def _is_pointwise(m):
 def _conv_branch(mods, x):
     """Run the modules of the conv branch in order; dense convs with a bias go through ops.conv2d_bias (same MIOpen
     kernels, fast bias gradient), 1x1 convs through PointwiseConvFn (batched GEMM)."""
-    for m in mods:
+    mods = list(mods)
+    i = 0
+    while i < len(mods):
+        m = mods[i]
         if isinstance(m, nn.Conv2d) and x.is_cuda:
             x = PointwiseConvFn.apply(x, m.weight, m.bias) if _is_pointwise(m) else conv2d_bias(x, m)
+        elif (_OWN_BN and type(m) is nn.BatchNorm2d and x.is_cuda and m.affine and x.dtype == torch.float32 and x.dim() == 4
+              and (m.training or not m.track_running_stats)):
+            # training-mode BatchNorm through our kernels; a directly following nn.ReLU is folded into them
+            relu = i + 1 < len(mods) and type(mods[i + 1]) is nn.ReLU
+            x = bn_relu_train(x, m, relu)
+            i += 1 if relu else 0
         else:
             x = m(x)
+        i += 1
     return x
+
+
+class _ConvBody(nn.Module):
+    """The conv branch of a block (MedMamba.py:338-346, without the trailing ReLU that shuffle_residual applies) as a module
+    of its own — the unit that MM_GRAPH_CONV=1 records into a pair of hipGraphs (forward / backward)."""
+
+    def __init__(self, mods):
+        super().__init__()
+        self.mods = nn.ModuleList(mods)       # the SAME module objects as in SS_Conv_SSM.conv33conv33conv11
+
+    def forward(self, x):
+        return _conv_branch(self.mods, x)
 
 
 def _side_stream(device):
@@ -427,6 +454,25 @@ class SS_Conv_SSM(nn.Module):
             left = conv_body(left)
         return shuffle_residual(left, x_cf, input, channel_first=True, ssm_scale=None, left_relu=True)
 
+    def _graphed_conv_body(self, mods, left):
+        """torch.cuda.make_graphed_callables over the conv branch for this input shape (built once per shape).  The BatchNorm
+        running statistics that its warm-up / capture passes touch are restored afterwards."""
+        cache = self.__dict__.setdefault("_conv_graphs", {})
+        key = (tuple(left.shape), left.device)
+        g = cache.get(key)
+        if g is None:
+            body = _ConvBody(mods)
+            bufs = [(b, b.detach().clone()) for b in body.buffers()]
+            sample = torch.randn_like(left).requires_grad_()
+            g = torch.cuda.make_graphed_callables(body, (sample,))
+            with torch.no_grad():
+                for b, saved in bufs:
+                    b.copy_(saved)
+            for prm in body.parameters():
+                prm.grad = None
+            cache[key] = g
+        return g
+
     def forward_modules(self, input):
         """MedMamba.py:349-357 module by module (hooks on any sub-module fire; used only when hooks are present)."""
         left, right = input.chunk(2, dim=-1)
@@ -453,6 +499,8 @@ class SS_Conv_SSM(nn.Module):
         fold_relu = isinstance(conv[-1], nn.ReLU)              # the trailing ReLU (:347) is applied by shuffle_residual
         mods = list(conv)[:-1] if fold_relu else list(conv)
         conv_body = lambda t: _conv_branch(mods, t)
+        if _GRAPH_CONV and self.training and torch.is_grad_enabled() and input.is_cuda:
+            conv_body = self._graphed_conv_body(mods, left)
         if _TWO_STREAMS and input.is_cuda:
             # the conv branch and the SS2D branch are independent (MedMamba.py:351-353): run the conv branch on a side
             # HIP stream so that its MIOpen kernels overlap the scan (autograd replays the backward on the same streams)

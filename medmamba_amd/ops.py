@@ -648,3 +648,60 @@ def patch_merge_ln_supported(C):
 def patch_merge_ln(x, gamma, beta, eps):
     _need_hip(x)
     return PatchMergeLNFn.apply(x, gamma, beta, eps)
+
+
+class BNReluFn(torch.autograd.Function):
+    """Training-mode nn.BatchNorm2d (+ the nn.ReLU behind it when relu=True) on contiguous NCHW tensors — the conv branch's
+    BN2+ReLU / BN3+ReLU / BN1 (MedMamba.py:338-344).  Updates running_mean / running_var in place like the module does; the
+    caller advances num_batches_tracked."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, relu):
+        x = x.float().contiguous()
+        gamma, beta = gamma.float().contiguous(), beta.float().contiguous()
+        B, C = x.shape[0], x.shape[1]
+        HW = x.numel() // (B * C)
+        dev = x.device
+        lib = _lib.lib()
+        y = torch.empty_like(x)
+        stats = torch.empty((2, C), device=dev, dtype=torch.float32)
+        ws = torch.empty((3 * C * lib.mm_bn_splits(B, C, HW),), device=dev, dtype=torch.float32)
+        with _lib.device_guard(dev):
+            rc = lib.mm_bn_relu_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), float(eps), float(momentum),
+                                    None if running_mean is None else running_mean.data_ptr(),
+                                    None if running_var is None else running_var.data_ptr(), y.data_ptr(), stats[0].data_ptr(),
+                                    stats[1].data_ptr(), ws.data_ptr(), int(bool(relu)), B, C, HW, _stream())
+        _lib.check(rc, "mm_bn_relu_fwd")
+        ctx.save_for_backward(x, gamma, beta, stats)
+        ctx.relu = bool(relu)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, stats = ctx.saved_tensors
+        B, C = x.shape[0], x.shape[1]
+        HW = x.numel() // (B * C)
+        dev = x.device
+        dy = dy.float().contiguous()
+        lib = _lib.lib()
+        dx = torch.empty_like(x)
+        dgb = torch.empty((2, C), device=dev, dtype=torch.float32)
+        ws = torch.empty((2 * C * lib.mm_bn_splits(B, C, HW),), device=dev, dtype=torch.float32)
+        with _lib.device_guard(dev):
+            rc = lib.mm_bn_relu_bwd(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), stats[0].data_ptr(),
+                                    stats[1].data_ptr(), dx.data_ptr(), dgb[0].data_ptr(), dgb[1].data_ptr(), ws.data_ptr(),
+                                    int(ctx.relu), B, C, HW, _stream())
+        _lib.check(rc, "mm_bn_relu_bwd")
+        return dx, dgb[0], dgb[1], None, None, None, None, None
+
+
+def bn_relu_train(x, bn, relu):
+    """`bn` (an nn.BatchNorm2d in training mode, affine, default momentum semantics) applied to x, optionally followed by
+    ReLU, through BNReluFn; num_batches_tracked advances as in the module's own forward."""
+    if bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+        momentum = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+    else:
+        momentum = 0.0 if bn.momentum is None else bn.momentum
+    rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
+    return BNReluFn.apply(x, bn.weight, bn.bias, rm, rv, bn.eps, momentum, relu)

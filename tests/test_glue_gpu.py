@@ -357,3 +357,31 @@ def test_ss2d_core_inference_with_fused_dt_projection(shape, layout, monkeypatch
     scale = max(1.0, ref.abs().max().item())
     assert (out.cpu() - ref).abs().max().item() <= 1e-4 * scale
     assert (out.cpu() - out_gemm.cpu()).abs().max().item() <= 2e-5 * scale
+
+
+@pytest.mark.parametrize("shape", [(64, 48, 56, 56), (8, 96, 28, 28), (4, 192, 14, 14), (3, 5, 7, 7), (2, 16, 1, 3), (64, 384, 7, 7)])
+@pytest.mark.parametrize("relu", [False, True])
+def test_own_batchnorm_relu_vs_torch(shape, relu):
+    """csrc/bn.hip: training-mode BatchNorm2d (+ ReLU) against torch.nn.BatchNorm2d (+ nn.ReLU) on the same device — output,
+    input / weight / bias gradients, running statistics and the batch counter (MedMamba.py:338-344)."""
+    from medmamba_amd.ops import bn_relu_train
+    B, C, H, W = shape
+    g = torch.Generator(device=DEV).manual_seed(sum(shape))
+    x = torch.randn(B, C, H, W, device=DEV, generator=g) * 2 + 0.5
+    dy = torch.randn(B, C, H, W, device=DEV, generator=g)
+    ref = torch.nn.BatchNorm2d(C).to(DEV).train()
+    with torch.no_grad():
+        ref.weight.copy_(torch.randn(C, device=DEV, generator=g)); ref.bias.copy_(torch.randn(C, device=DEV, generator=g) * 0.3)
+    own = torch.nn.BatchNorm2d(C).to(DEV).train()
+    own.load_state_dict(ref.state_dict())
+    xr, xo = x.clone().requires_grad_(), x.clone().requires_grad_()
+    for step in range(2):                                   # two steps: running statistics accumulate
+        yr = ref(xr); yr = torch.relu(yr) if relu else yr
+        yo = bn_relu_train(xo, own, relu)
+    yr.backward(dy); yo.backward(dy)
+    close = lambda a, b, tol: float((a - b).abs().max()) <= tol * max(1.0, float(b.abs().max()))
+    assert close(yo, yr, 2e-6)
+    assert close(xo.grad, xr.grad, 2e-5)
+    assert close(own.weight.grad, ref.weight.grad, 2e-5) and close(own.bias.grad, ref.bias.grad, 2e-5)
+    assert close(own.running_mean, ref.running_mean, 1e-6) and close(own.running_var, ref.running_var, 2e-6)
+    assert int(own.num_batches_tracked) == int(ref.num_batches_tracked) == 2
