@@ -38,6 +38,9 @@ _FOLD_BN = __import__("os").environ.get("MM_FOLD_BN", "1") == "1"         # MM_F
 # 80 launches become 2); the SS2D branch stays eager.  Off by default: measured in DESIGN.md §4.5.
 _GRAPH_CONV = __import__("os").environ.get("MM_GRAPH_CONV", "0") == "1"
 _OWN_BN = __import__("os").environ.get("MM_OWN_BN", "1") == "1"         # MM_OWN_BN=0: training-mode BatchNorm / ReLU through MIOpen / ATen
+# MM_GRAPH_BLOCK_MAX_L=n (experimental, training): blocks whose images have at most n positions are replayed from hipGraphs
+# (forward and backward one launch each) — the stages where the step is bound by the host's launch rate.  0 = off.
+_GRAPH_BLOCK_MAX_L = int(__import__("os").environ.get("MM_GRAPH_BLOCK_MAX_L", "0"))
 _SIDE_STREAMS = {}
 # images with at least this many positions start the side stream when the scan kernel is queued (see SS_Conv_SSM.forward)
 _LATE_SIDE_MIN_L = int(__import__("os").environ.get("MM_LATE_SIDE_MIN_L", "2048"))
@@ -535,6 +538,22 @@ class SS_Conv_SSM(nn.Module):
         return shuffle_residual(left, x_cf, input, channel_first=True, ssm_scale=scale, left_relu=fold_relu)
 
 
+class _GraphableBlock(nn.Module):
+    """SS_Conv_SSM with its per-step DropPath factor as an explicit tensor argument (what a hipGraph capture needs)."""
+
+    def __init__(self, blk):
+        super().__init__()
+        self.blk = blk
+
+    def forward(self, x, factor):
+        prev = getattr(self.blk, "_dp_factor", None)
+        self.blk._dp_factor = factor
+        try:
+            return self.blk(x)
+        finally:
+            self.blk._dp_factor = prev
+
+
 class VSSLayer(nn.Module):
     """One stage: `depth` blocks then an optional downsample (MedMamba.py:359-422)."""
 
@@ -555,9 +574,40 @@ class VSSLayer(nn.Module):
                     nn.init.kaiming_uniform_(p.clone().detach_(), a=math.sqrt(5))
         self.downsample = downsample(dim=dim, norm_layer=norm_layer) if downsample is not None else None
 
+    def _graphed(self, blk, x):
+        """torch.cuda.make_graphed_callables over one whole block (both branches, both streams) for this input shape: the
+        block's ~80 launches per step become 2 graph launches.  The DropPath factor of the step goes in as a tensor argument
+        (a graph would otherwise replay the factor tensor of its capture).  BatchNorm statistics touched by the warm-up /
+        capture passes are restored."""
+        cache = blk.__dict__.setdefault("_block_graphs", {})
+        key = (tuple(x.shape), x.device)
+        g = cache.get(key)
+        if g is None:
+            wrap = _GraphableBlock(blk)
+            bufs = [(b, b.detach().clone()) for b in blk.buffers()]
+            sx = torch.randn_like(x).requires_grad_()
+            sf = torch.ones(x.shape[0], device=x.device, dtype=torch.float32)
+            g = torch.cuda.make_graphed_callables(wrap, (sx, sf))
+            with torch.no_grad():
+                for b, saved in bufs:
+                    b.copy_(saved)
+            for prm in blk.parameters():
+                prm.grad = None
+            cache[key] = g
+        f = getattr(blk, "_dp_factor", None)
+        if f is None:
+            f = blk.drop_path.factor(x)
+            f = torch.ones(x.shape[0], device=x.device, dtype=torch.float32) if f is None else f.reshape(-1)
+        return g(x, f)
+
     def forward(self, x):
+        graph = (_GRAPH_BLOCK_MAX_L > 0 and self.training and torch.is_grad_enabled() and x.is_cuda and not self.use_checkpoint
+                 and x.shape[1] * x.shape[2] <= _GRAPH_BLOCK_MAX_L and x.requires_grad)
         for blk in self.blocks:
-            x = checkpoint.checkpoint(blk, x) if self.use_checkpoint else blk(x)
+            if graph and not _has_hooks(blk):
+                x = self._graphed(blk, x)
+            else:
+                x = checkpoint.checkpoint(blk, x) if self.use_checkpoint else blk(x)
         return x if self.downsample is None else self.downsample(x)
 
 

@@ -426,3 +426,33 @@ def test_graphed_inference_matches_eager():
         assert float((got - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max()))
     with pytest.raises(RuntimeError):
         g(torch.randn(2, 3, 64, 64, device=DEV))
+
+
+def test_graphed_blocks_match_eager(monkeypatch):
+    """MM_GRAPH_BLOCK_MAX_L (experimental): whole blocks replayed from hipGraphs in training — same loss, gradients and
+    BatchNorm statistics as eager execution, over several steps (static input / gradient buffers are reused)."""
+    from medmamba_amd import modules
+    x = torch.randn(4, 3, 64, 64, device=DEV)
+    y = torch.randint(0, 3, (4,), device=DEV)
+    res = {}
+    for graphed in (False, True):
+        monkeypatch.setattr(modules, "_GRAPH_BLOCK_MAX_L", (1 << 20) if graphed else 0)
+        torch.manual_seed(5)
+        net = modules.VSSM(num_classes=3, depths=[1, 2, 1, 1], dims=[16, 32, 64, 128], drop_path_rate=0.0).to(DEV).train()
+        opt = torch.optim.SGD(net.parameters(), lr=1e-2)
+        losses = []
+        for _ in range(3):
+            opt.zero_grad(set_to_none=True)
+            loss = torch.nn.functional.cross_entropy(net(x), y)
+            loss.backward()
+            opt.step()
+            losses.append(float(loss))
+        res[graphed] = (losses, {k: v.clone() for k, v in net.state_dict().items()})
+    for a, b in zip(res[True][0], res[False][0]):
+        assert abs(a - b) <= 2e-5 * max(1.0, abs(b)), (res[True][0], res[False][0])
+    for k, v in res[False][1].items():
+        w = res[True][1][k]
+        if v.dtype.is_floating_point:
+            assert float((v - w).abs().max()) <= 1e-4 * max(1e-2, float(v.abs().max())), k
+        else:
+            assert torch.equal(v, w), k

@@ -18,4 +18,4 @@ torch.cuda.synchronize()
 pr = cProfile.Profile(); pr.enable()
 for _ in range(5): step()
 pr.disable(); torch.cuda.synchronize()
-st = pstats.Stats(pr); st.sort_stats("tottime").print_stats(45)
+st = pstats.Stats(pr); st.sort_stats("tottime").print_stats(45); st.sort_stats("cumulative").print_stats(70)
