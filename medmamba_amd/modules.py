@@ -340,7 +340,7 @@ class SS2D(nn.Module):
 
     def forward(self, x, **kwargs):
         """(B, H, W, d_model) -> (B, H, W, d_model) (MedMamba.py:288-305)."""
-        if _has_hooks(self):
+        if _has_hooks(self) or self.d_state != 16:
             return self.forward_modules(x)
         B, H, W, _ = x.shape
         return self.forward_cf(x).transpose(1, 2).reshape(B, H, W, -1)
@@ -484,7 +484,9 @@ class SS_Conv_SSM(nn.Module):
         return channel_shuffle(torch.cat((left, right), dim=-1), groups=2) + input
 
     def forward(self, input):
-        if _has_hooks(self) or not isinstance(self.drop_path, DropPath):
+        # the fused plane-wise core is built for the reference's d_state = 16 (MedMamba.py:329,457); any other d_state takes the
+        # reference's own op chain around selective_scan_fn, which runs it as 16-state slices on the same kernels
+        if _has_hooks(self) or not isinstance(self.drop_path, DropPath) or self.self_attention.d_state != 16:
             return self.forward_modules(input)
         ln_ok = isinstance(self.ln_1, nn.LayerNorm) and self.ln_1.elementwise_affine and self.ln_1.bias is not None \
             and input.shape[-1] % 2 == 0 and input.shape[-1] // 2 <= 512

@@ -86,11 +86,14 @@ def _check_inputs(u, delta, A, B, C, D, z, delta_bias, return_last_state):
                            f"A{tuple(A.shape)} B{tuple(B.shape)} C{tuple(C.shape)}")
     if dim % G != 0:
         raise RuntimeError("selective_scan_fn: dim must be divisible by the number of B/C groups")
-    if N != 16:
-        raise NotImplementedError("only d_state = 16 is implemented (every MedMamba block: MedMamba.py:329,457)")
+    if N < 1:
+        raise RuntimeError("selective_scan_fn: d_state must be >= 1")
     for name, t in (("D", D), ("delta_bias", delta_bias)):
         if t is not None and t.shape != (dim,):
             raise RuntimeError(f"selective_scan_fn: {name} must have shape ({dim},)")
+
+
+_KERNEL_STATES = 16     # mm::kNState: states per channel inside the kernels
 
 
 def _f32_rows(t):
@@ -282,7 +285,27 @@ def selective_scan_fn(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_
                       return_last_state=False):
     """Drop-in for mamba_ssm's selective_scan_fn on the variant MedMamba uses (MedMamba.py:273-279).
 
-    u, delta: (batch, dim, L); A: (dim, 16); B, C: (batch, G, 16, L) (may be non-contiguous views with
-    unit stride along L); D, delta_bias: (dim,).  Returns (batch, dim, L) float32, contiguous."""
+    u, delta: (batch, dim, L); A: (dim, N); B, C: (batch, G, N, L) (may be non-contiguous views with
+    unit stride along L); D, delta_bias: (dim,).  Returns (batch, dim, L) float32, contiguous.
+
+    The kernels hold N = 16 states per channel (one per lane of a 16-lane group; every MedMamba block uses d_state = 16,
+    MedMamba.py:329,457).  The states of one channel never interact — y_t = sum_n C_n,t x_n,t + D u_t — so any other
+    d_state runs as ceil(N / 16) launches over 16-state slices whose outputs add up: a short slice is filled with states
+    that have B = C = 0 (they stay zero and contribute nothing to y or to any gradient), D rides on the first slice only.
+    Autograd sums du / ddelta / dbias over the slices and cuts dA / dB / dC back to the real states."""
     _check_inputs(u, delta, A, B, C, D, z, delta_bias, return_last_state)
-    return SelectiveScanFn.apply(u, delta, A, B, C, D, delta_bias, delta_softplus, 0)
+    N = A.shape[1]
+    if N == _KERNEL_STATES:
+        return SelectiveScanFn.apply(u, delta, A, B, C, D, delta_bias, delta_softplus, 0)
+    y = None
+    for n0 in range(0, N, _KERNEL_STATES):
+        n1 = min(N, n0 + _KERNEL_STATES)
+        Ak, Bk, Ck = A[:, n0:n1], B[:, :, n0:n1], C[:, :, n0:n1]
+        fill = _KERNEL_STATES - (n1 - n0)
+        if fill:
+            Ak = torch.cat([Ak.float(), Ak.new_full((A.shape[0], fill), -1.0, dtype=torch.float32)], dim=1)
+            zeros = B.new_zeros((B.shape[0], B.shape[1], fill, B.shape[3]), dtype=torch.float32)
+            Bk, Ck = torch.cat([Bk.float(), zeros], dim=2), torch.cat([Ck.float(), zeros], dim=2)
+        yk = SelectiveScanFn.apply(u, delta, Ak, Bk, Ck, D if n0 == 0 else None, delta_bias, delta_softplus, 0)
+        y = yk if y is None else y + yk
+    return y
