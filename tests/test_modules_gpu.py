@@ -77,7 +77,7 @@ def test_tiny_vssm_logits_loss_and_grads():
     assert worst <= 5e-3, worst      # fp32 training-mode grads through 4 blocks incl. BatchNorm batch statistics
 
 
-@pytest.mark.parametrize("size", ["T", "S", "B"])
+@pytest.mark.parametrize("size", ["T", "S", "Te", "B"])
 def test_seed_kat_full_model_logits(size):
     """BASELINE config 1 (T, S at 224x224) and the config-5 model (B at 384x384: 96x96 planes, D up to 1024, R up to 32):
     seed 42 -> same init -> logits of the reference (CPU, restated scan)."""
