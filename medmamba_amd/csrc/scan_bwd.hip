@@ -80,8 +80,8 @@ __global__ __launch_bounds__(512) void scan_bwd_kernel(const BwdParams p) {
   float* sAcc = smem + 2 * 2 * kNState * TS;           // [2 buf][nwaves][2][16][TS]   dB, dC partial sums, one slab per wave
   float* wl = smem + (2 + 2 * nwaves) * 2 * kNState * TS + wave * (3 * CH * TS);
   float* s_u = wl;                                     // u      -> du   (in place)
-  float* s_dl = wl + CH * TS;                          // delta' -> ddelta' (in place)
-  float* s_g = wl + 2 * CH * TS;                       // dout
+  float* s_dl = wl + CH * TS;                          // delta'
+  float* s_g = wl + 2 * CH * TS;                       // dout -> d(delta') (in place)
 
   // ---- recurrence identity
   const int g = lane >> 4, c = lane & 15;
@@ -133,12 +133,20 @@ __global__ __launch_bounds__(512) void scan_bwd_kernel(const BwdParams p) {
     dDacc[i] = 0.f;
     dbacc[i] = 0.f;
   }
-  // B/C tile = 2 x 16 rows x 8 quads = 256 float4, spread over the workgroup's threads (one per thread for >= 4 waves)
-  const int bc_which = (tid >> 7) & 1, bc_n = (tid >> 3) & 15, bc_q = tid & 7;
-  const bool bc_mine = tid < 256;
-  const int bc_off = (int)(bc_n * (bc_which ? p.C_sn : p.B_sn)) * 4;
+  // B/C tile = 2 x 16 rows x 8 quads = 256 float4, spread over the workgroup's threads: one per thread for >= 4 waves, two
+  // for 2 or 3 waves (quad index tid, tid + nthreads), both prefetched in registers one tile ahead
+  int bc_which[2], bc_n[2], bc_q[2], bc_off[2];
+  bool bc_mine[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int idx = tid + k * nthreads;
+    bc_which[k] = (idx >> 7) & 1; bc_n[k] = (idx >> 3) & 15; bc_q[k] = idx & 7;
+    bc_mine[k] = idx < 256 && (k == 0 || nthreads < 256);
+    bc_off[k] = (int)(bc_n[k] * (bc_which[k] ? p.C_sn : p.B_sn)) * 4;
+  }
+  const bool bc_pref = nthreads >= 128;         // a single wave (tiny problems) stages its four quads per thread without prefetch
 
-  float4 pu[NLD], pd[NLD], pg[NLD], pbc;
+  float4 pu[NLD], pd[NLD], pg[NLD], pbc[2];
   auto issue_loads = [&](int t0) {
     const int t = t0 + 4 * q;
 #pragma unroll
@@ -147,7 +155,10 @@ __global__ __launch_bounds__(512) void scan_bwd_kernel(const BwdParams p) {
       pd[i] = load_quad<VEC, VEC>(rd, doff[i], t, p.L, rev, rvalid[i]);
       pg[i] = load_quad<VEC, VEC>(rg, ooff[i], t, p.L, rev, rvalid[i]);
     }
-    if (nthreads >= 256) pbc = load_quad<VEC, VEC>(bc_which ? rC : rB, bc_off, t0 + 4 * bc_q, p.L, rev, bc_mine);
+    if (bc_pref) {
+      pbc[0] = load_quad<VEC, VEC>(bc_which[0] ? rC : rB, bc_off[0], t0 + 4 * bc_q[0], p.L, rev, bc_mine[0]);
+      if (nthreads < 256) pbc[1] = load_quad<VEC, VEC>(bc_which[1] ? rC : rB, bc_off[1], t0 + 4 * bc_q[1], p.L, rev, bc_mine[1]);
+    }
   };
   // Reversed directions on the vector path keep their quads in MEMORY order (no per-component selects on loads / stores);
   // a reversed tile lies mirrored in LDS (time quad q in column QL-1-q, step e in component 3-e) and the loops below
@@ -210,9 +221,12 @@ __global__ __launch_bounds__(512) void scan_bwd_kernel(const BwdParams p) {
       *reinterpret_cast<float4*>(s_dl + off) = dl;
       *reinterpret_cast<float4*>(s_g + off) = pg[i];
     }
-    if (nthreads >= 256) {
-      if (bc_mine) *reinterpret_cast<float4*>(sBC + ((buf * 2 + bc_which) * kNState + bc_n) * TS + 4 * (revm ? QL - 1 - bc_q : bc_q)) = pbc;
-    } else {   // fewer than 4 waves (tiny problems): every thread stages several quads, no prefetch
+    if (bc_pref) {
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+        if (bc_mine[k])
+          *reinterpret_cast<float4*>(sBC + ((buf * 2 + bc_which[k]) * kNState + bc_n[k]) * TS + 4 * (revm ? QL - 1 - bc_q[k] : bc_q[k])) = pbc[k];
+    } else {   // one wave: every thread stages four quads, no prefetch
       for (int idx = tid; idx < 256; idx += nthreads) {
         const int w_ = (idx >> 7) & 1, n_ = (idx >> 3) & 15, q_ = idx & 7;
         *reinterpret_cast<float4*>(sBC + ((buf * 2 + w_) * kNState + n_) * TS + 4 * (revm ? QL - 1 - q_ : q_)) =
@@ -315,9 +329,7 @@ __global__ __launch_bounds__(512) void scan_bwd_kernel(const BwdParams p) {
             const unsigned q0 = r16[0], q1 = r16[1];
             pa = __builtin_bit_cast(float, q0) + __builtin_bit_cast(float, q1);   // rows 0,1: ddelta'   rows 2,3: du - D*g
           }
-          // d softplus / d raw = sigmoid(raw) = 1 - exp(-delta')  (series for tiny delta' keeps it relative-accurate)
-          const float sg = SP ? (dl < 9.765625e-4f ? dl * (1.f - 0.5f * dl) : 1.f - __builtin_amdgcn_exp2f(-dl * kLog2e)) : 1.f;
-          (&ddl4.x)[RV ? 3 - e : e] = pa * sg;
+          (&ddl4.x)[RV ? 3 - e : e] = pa;      // d(delta'); the softplus derivative is applied once per element in phase 3
           (&du4.x)[RV ? 3 - e : e] = fmaf(Dc, gt, pa);
           // dB/dC: 8 values x 16 lanes -> one value per lane (halving butterfly), then one LDS atomic per lane
           {
@@ -348,7 +360,7 @@ __global__ __launch_bounds__(512) void scan_bwd_kernel(const BwdParams p) {
             if (!(c & 2)) accb[to + e] = w1;       // this wave's own slab: a plain ds_write_b32
           }
         }
-        if (g == 0) *reinterpret_cast<float4*>(s_dl + c * TS + colof(to)) = ddl4;
+        if (g == 0) *reinterpret_cast<float4*>(s_g + c * TS + colof(to)) = ddl4;   // over the consumed dout quad; delta' stays
         if (g == 2) *reinterpret_cast<float4*>(s_u + c * TS + colof(to)) = du4;
       }
     }
@@ -365,7 +377,15 @@ __global__ __launch_bounds__(512) void scan_bwd_kernel(const BwdParams p) {
       const int t = t0 + 4 * q;
       const int off = (RPI * i + r) * TS + 4 * qc;
       const float4 vdu = *reinterpret_cast<const float4*>(s_u + off);
-      const float4 vdd = *reinterpret_cast<const float4*>(s_dl + off);
+      float4 vdd = *reinterpret_cast<const float4*>(s_g + off);
+      if (SP) {   // d softplus / d raw = sigmoid(raw) = 1 - exp(-delta')  (series for tiny delta' keeps it relative-accurate)
+        const float4 dlq = *reinterpret_cast<const float4*>(s_dl + off);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float dl = f4get(dlq, e);
+          (&vdd.x)[e] *= dl < 9.765625e-4f ? dl * (1.f - 0.5f * dl) : 1.f - __builtin_amdgcn_exp2f(-dl * kLog2e);
+        }
+      }
       store_quad<VEC, VEC>(rdu, ooff[i], t, p.L, rev, rvalid[i], vdu);
       store_quad<VEC, VEC>(rdd, ooff[i], t, p.L, rev, rvalid[i], vdd);
 #pragma unroll
@@ -440,17 +460,14 @@ int scan_bwd_launch(const mm_scan_args* a, hipStream_t stream) {
   const int waves_needed = (p.H + CH - 1) / CH;
   // waves per workgroup (<= 8: register budget).  A direction that fits ONE workgroup (<= 128 channels) gets one when there are
   // enough (batch, direction) pairs for every CU: dB/dC then leave with plain stores (measured, S/Bz=64 stage 1: 1.51 ms
-  // with 256 x 6 waves vs 1.58-1.65 ms with 512 x 3 waves + atomics).  Otherwise 4-wave workgroups, fewer when the pairs
-  // alone cannot give every CU two workgroups — the price is fp32 atomics on dB/dC from the workgroups that share a
+  // with 256 x 6 waves vs 1.58-1.65 ms with 512 x 3 waves + atomics).  Otherwise 4-wave workgroups — the price is fp32 atomics on dB/dC from the workgroups that share a
   // direction (measured: 4-wave workgroups beat 6- and 8-wave ones at stages 2-4: 0.62 vs 0.76 / 0.80 ms, 0.32 vs 0.34 ms)
   int maxw;
   const int forced = (a->variant >> 16) & 0xff;              // tuning override
   if (forced > 0) maxw = forced > 8 ? 8 : forced;
   else if (waves_needed <= 8 && (long)a->batch * a->G >= 256) maxw = 8;
-  else {
-    maxw = 4;
-    while (maxw > 2 && (long)a->batch * a->G * ((waves_needed + maxw - 1) / maxw) < 512) maxw >>= 1;
-  }
+  else maxw = 4;   // never fewer: 2-wave workgroups double the atomics and lost everywhere they were measured (B, Bz = 32,
+                   // 96x96 stage: 4.87 ms with 512 x 2 waves, 3.24 ms with 256 x 4, 4.25 ms with 128 x 8)
   const int ncw0 = (waves_needed + maxw - 1) / maxw;
   const int waves = (waves_needed + ncw0 - 1) / ncw0;
   p.CW = waves * CH;
