@@ -358,7 +358,8 @@ namespace mm {
 int plan_fwd_variant(int batch, int G, int H, int L) {
   (void)L;
   const long seqs = (long)batch * G * H;
-  if (seqs / 16 >= 3072) return 4;     // >= 3 waves per SIMD at 4 states per lane (LEAN variant)
+  if (seqs / 16 >= 2048) return 4;     // >= 2 waves per SIMD at 4 states per lane (B, Bz = 32, 48x48 stage: 2048 waves of 4
+                                       // states 0.33 ms vs 4096 waves of 2 states 0.44 ms); LEAN from 3 per SIMD, see below
   if (seqs / 8 >= 1024) return 2;      // fewer sequences: halve the states per lane to double the wave count
   return 1;
 }
