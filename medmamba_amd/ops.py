@@ -61,6 +61,16 @@ def _cm2d(t):
     return t.permute(1, 0, 2).reshape(D, B * L)
 
 
+def _joined_halves(a, b):
+    """(B, 2D, L) view over `a` followed by `b` when the two (B, D, L) tensors are the channel halves of one buffer, else None."""
+    if (a.shape != b.shape or a.stride() != b.stride() or a.dtype != torch.float32 or b.dtype != torch.float32
+            or a.untyped_storage().data_ptr() != b.untyped_storage().data_ptr()
+            or b.storage_offset() != a.storage_offset() + a.shape[1] * a.stride(1)):
+        return None
+    B, D, L = a.shape
+    return a.as_strided((B, 2 * D, L), a.stride(), a.storage_offset())
+
+
 def _pl(t):
     """(pointer, batch stride, channel stride) of a (B, D, L) plane tensor with unit stride along L."""
     assert t.stride(2) == 1 or t.shape[2] == 1
@@ -154,7 +164,16 @@ class InProjFn(torch.autograd.Function):
         D = weight.shape[0] // 2
         w0, w1 = weight[:D], weight[D:]
         dw = torch.empty_like(weight)
-        if ctx.cm:
+        g = _joined_halves(dx_cf, dz_cf)
+        if g is not None:              # the SS2D core hands both gradients back as halves of one (B, 2D, L) buffer
+            if ctx.cm and _is_cm(g):
+                g2, x2 = _cm2d(g), x.view(Bsz * L, dm)
+                dx = torch.mm(g2.t(), weight).view(Bsz, L, dm)
+                torch.mm(g2, x2, out=dw)
+            else:
+                dx = torch.bmm(g.transpose(1, 2), weight.unsqueeze(0).expand(Bsz, -1, -1))
+                torch.sum(torch.bmm(g, x), dim=0, out=dw)
+        elif ctx.cm:
             gx, gz, x2 = _cm2d(dx_cf), _cm2d(dz_cf), x.view(Bsz * L, dm)                         # (D, B*L) each
             dx = torch.mm(gx.t(), w0)
             dx.addmm_(gz.t(), w1)
@@ -349,7 +368,10 @@ class SS2DCoreFn(torch.autograd.Function):
         dev = m.device
         dy = _rows(dy)
         dout2 = _planes(Bsz, 2 * D, L, dev, cm)         # channel block 0: dm, block 1: its plane transpose
-        dz = _planes(Bsz, D, L, dev, cm)
+        # d(x_cf) | d(z_cf) as the two channel halves of ONE buffer, the layout in_proj produced them in: its backward then
+        # runs one GEMM per product over all 2D rows (InProjFn.backward)
+        dxz = _planes(Bsz, 2 * D, L, dev, cm)
+        dz = dxz[:, D:]
         lib = _lib.lib()
         ws = torch.empty((lib.mm_ln_gate_rows(Bsz, D, L), 2 * D), device=dev, dtype=torch.float32)
         with _lib.device_guard(dev):
@@ -411,7 +433,7 @@ class SS2DCoreFn(torch.autograd.Function):
         dcw = dcb = None
         if fused_conv:
             # d(u2) = projection part (du2) + the scan's two direction pairs (du4), summed inside the conv's backward kernel
-            dxc = _planes(Bsz, D, L, dev, cm)
+            dxc = dxz[:, :D]
             wsc = torch.empty((Bsz, D * lib.mm_dwconv_silu_cross_strips(H, W), 10), device=dev, dtype=torch.float32)
             with _lib.device_guard(dev):
                 rc = lib.mm_dwconv_silu_cross_bwd(*_pl(du2), *_pl(du4), *_pl(x_cf), conv_w.data_ptr(),
