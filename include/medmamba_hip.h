@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MM_ABI_VERSION 16
+#define MM_ABI_VERSION 17
 
 enum mm_status {
   MM_OK = 0,
@@ -218,6 +218,17 @@ int mm_patch_merge_ln_fwd(const float* x, const float* gamma, const float* beta,
                           int batch, int H, int W, int C, void* stream);
 int mm_patch_merge_ln_bwd(const float* dy, const float* x, const float* gamma, const float* mu, const float* rstd, float* dinp,
                           float* ws, int batch, int H, int W, int C, void* stream);
+
+/* PatchEmbed2D back half (MedMamba.py:70-76: `x = self.proj(x).permute(0, 2, 3, 1)`, then LayerNorm(C)) in one pass:
+ * x (batch, C, HW) contiguous NCHW conv output -> out (batch, HW, C) NHWC rows = LN(x^T) * gamma + beta, statistics mu / rstd
+ * (batch * HW).  Backward: dy (batch, HW, C) -> dx (batch, C, HW) and partial sums ws[row * 2*C + (0: dgamma | C: dbeta) + c],
+ * row < mm_nchw_ln_rows_ws_rows(batch, HW) (the caller sums the rows).  mm_nchw_ln_rows_supported(C): C <= 512. */
+int mm_nchw_ln_rows_supported(int C);
+int mm_nchw_ln_rows_ws_rows(int batch, int HW);
+int mm_nchw_ln_rows_fwd(const float* x, const float* gamma, const float* beta, float eps, float* out, float* mu, float* rstd,
+                        int batch, int C, int HW, void* stream);
+int mm_nchw_ln_rows_bwd(const float* dy, const float* x, const float* gamma, const float* mu, const float* rstd, float* dx,
+                        float* ws, int batch, int C, int HW, void* stream);
 
 /* Training-mode BatchNorm2d of the conv branch (MedMamba.py:338, 340, 343) with the nn.ReLU that follows two of them (:341,
  * :344) folded in.  x, y, dy, dx: contiguous NCHW (batch, C, HW).  Semantics of torch.nn.BatchNorm2d in training mode: batch

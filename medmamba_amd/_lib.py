@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "lib", "libmedmamba_hip.so")
 
-ABI_VERSION = 16        # == MM_ABI_VERSION of include/medmamba_hip.h (checked when the library is loaded)
+ABI_VERSION = 17        # == MM_ABI_VERSION of include/medmamba_hip.h (checked when the library is loaded)
 _f32p = ctypes.c_void_p
 _i64 = ctypes.c_int64
 
@@ -69,6 +69,10 @@ SYMBOLS = {
     "mm_patch_merge_ln_rows": (ctypes.c_int, [ctypes.c_int] * 3),
     "mm_patch_merge_ln_fwd": (ctypes.c_int, [_f32p, _f32p, _f32p, ctypes.c_float, _f32p, _f32p, _f32p] + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
     "mm_patch_merge_ln_bwd": (ctypes.c_int, [_f32p] * 7 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
+    "mm_nchw_ln_rows_supported": (ctypes.c_int, [ctypes.c_int]),
+    "mm_nchw_ln_rows_ws_rows": (ctypes.c_int, [ctypes.c_int] * 2),
+    "mm_nchw_ln_rows_fwd": (ctypes.c_int, [_f32p, _f32p, _f32p, ctypes.c_float, _f32p, _f32p, _f32p] + [ctypes.c_int] * 3 + [ctypes.c_void_p]),
+    "mm_nchw_ln_rows_bwd": (ctypes.c_int, [_f32p] * 7 + [ctypes.c_int] * 3 + [ctypes.c_void_p]),
     "mm_bn_splits": (ctypes.c_int, [ctypes.c_int] * 3),
     "mm_bn_relu_fwd": (ctypes.c_int, [_f32p, _f32p, _f32p, ctypes.c_float, ctypes.c_float, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p]
                        + [ctypes.c_int] * 4 + [ctypes.c_void_p]),

@@ -25,8 +25,8 @@ import torch.nn.functional as F
 import torch.utils.checkpoint as checkpoint
 
 from . import _lib
-from .ops import (PointwiseConvFn, block_split, block_split_infer, bn_relu_train, conv2d_bias, patch_merge_ln,
-                  patch_merge_ln_supported, dwconv_silu_cross, in_proj_cf, out_proj_cf, shuffle_residual,
+from .ops import (PointwiseConvFn, block_split, block_split_infer, bn_relu_train, conv2d_bias, nchw_ln_rows,
+                  nchw_ln_rows_supported, patch_merge_ln, patch_merge_ln_supported, dwconv_silu_cross, in_proj_cf, out_proj_cf, shuffle_residual,
                   ss2d_conv_core, ss2d_core)
 from .selective_scan_interface import CROSS_SCAN_K_OF_G, cross_scan_fn, selective_scan_fn
 
@@ -142,8 +142,13 @@ class PatchEmbed2D(nn.Module):
         self.norm = norm_layer(embed_dim) if norm_layer is not None else None
 
     def forward(self, x):
-        x = self.proj(x).permute(0, 2, 3, 1)
-        return x if self.norm is None else self.norm(x)
+        x = self.proj(x)
+        n = self.norm
+        if (x.is_cuda and type(n) is nn.LayerNorm and n.elementwise_affine and n.bias is not None and not _has_hooks(self)
+                and nchw_ln_rows_supported(x.shape[1])):
+            return nchw_ln_rows(x, n.weight, n.bias, n.eps)          # permute + LayerNorm, one pass over HBM each way
+        x = x.permute(0, 2, 3, 1)
+        return x if n is None else n(x)
 
 
 class PatchMerging2D(nn.Module):

@@ -672,6 +672,50 @@ def patch_merge_ln(x, gamma, beta, eps):
     return PatchMergeLNFn.apply(x, gamma, beta, eps)
 
 
+class NchwLNRowsFn(torch.autograd.Function):
+    """PatchEmbed2D's permute + LayerNorm (MedMamba.py:70-76) in one kernel each way: x (B, C, H, W) contiguous NCHW (the strided
+    conv's output) -> (B, H, W, C) normalised NHWC rows; the backward returns d(x) in NCHW for the conv's own backward."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        x, gamma, beta = x.float().contiguous(), gamma.float().contiguous(), beta.float().contiguous()
+        B, C, H, W = x.shape
+        dev = x.device
+        out = torch.empty((B, H, W, C), device=dev, dtype=torch.float32)
+        stats = torch.empty((2, B * H * W), device=dev, dtype=torch.float32)
+        with _lib.device_guard(dev):
+            rc = _lib.lib().mm_nchw_ln_rows_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), float(eps), out.data_ptr(),
+                                                stats[0].data_ptr(), stats[1].data_ptr(), B, C, H * W, _stream())
+        _lib.check(rc, "mm_nchw_ln_rows_fwd")
+        ctx.save_for_backward(x, gamma, stats)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, stats = ctx.saved_tensors
+        B, C, H, W = x.shape
+        dev = x.device
+        dy = dy.float().contiguous()
+        lib = _lib.lib()
+        dx = torch.empty_like(x)
+        ws = torch.empty((lib.mm_nchw_ln_rows_ws_rows(B, H * W), 2, C), device=dev, dtype=torch.float32)
+        with _lib.device_guard(dev):
+            rc = lib.mm_nchw_ln_rows_bwd(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(),
+                                         dx.data_ptr(), ws.data_ptr(), B, C, H * W, _stream())
+        _lib.check(rc, "mm_nchw_ln_rows_bwd")
+        s = ws.sum(0)
+        return dx, s[0], s[1], None
+
+
+def nchw_ln_rows_supported(C):
+    return bool(_lib.lib().mm_nchw_ln_rows_supported(int(C)))
+
+
+def nchw_ln_rows(x, gamma, beta, eps):
+    _need_hip(x)
+    return NchwLNRowsFn.apply(x, gamma, beta, eps)
+
+
 class BNReluFn(torch.autograd.Function):
     """Training-mode nn.BatchNorm2d (+ the nn.ReLU behind it when relu=True) on contiguous NCHW tensors — the conv branch's
     BN2+ReLU / BN3+ReLU / BN1 (MedMamba.py:338-344).  Updates running_mean / running_var in place like the module does; the
