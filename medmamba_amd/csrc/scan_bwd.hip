@@ -50,22 +50,29 @@ struct BwdParams {
 
 __device__ __forceinline__ float f4get(const float4& v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
 
-constexpr int NS = 4;            // states per lane
-constexpr int CH = 16;           // channels per wave
 constexpr int T = 32;            // steps per tile
 constexpr int TS = T + 4;        // LDS row stride (floats)
 constexpr int QL = T / 4;        // float4 columns per row = 8
 constexpr int RPI = kWave / QL;  // rows per load instruction = 8
-constexpr int NLD = CH / RPI;    // row-loads per lane per tensor per tile = 2
 constexpr int NSUB = T / kChunk; // 16-step sub-tiles per tile = 2
+// NS = states per lane: 4 (16 channels per wave, 4 state groups) or 2 (8 channels per wave, 8 state groups: twice the waves
+// for the same problem at half the registers — the 56x56 stage of T/S and the 96x96 stage of B offer fewer than 2 waves per
+// SIMD at 4 states per lane)
+constexpr int ch_of(int ns) { return 4 * ns; }                 // channels per wave
+constexpr int tsa_of(int ns) { return ns == 4 ? TS : T + 1; }  // row stride of the dB/dC slabs (12 waves of NS = 2 must fit LDS)
+constexpr int maxthreads_of(int ns) { return ns == 4 ? 512 : 768; }
 
 
 // keep + (send of the DPP partner lane)
 template <int CTRL>
 __device__ __forceinline__ float dpp_add(float keep, float send) { return keep + dpp_f<CTRL>(send); }
 
-template <bool VEC, bool SP>
-__global__ __launch_bounds__(512) void scan_bwd_kernel(const BwdParams p) {
+template <int NS, bool VEC, bool SP>
+__global__ __launch_bounds__(maxthreads_of(NS)) void scan_bwd_kernel(const BwdParams p) {
+  constexpr int CH = ch_of(NS);          // channels per wave
+  constexpr int NG = kNState / NS;       // state groups = lanes per channel
+  constexpr int NLD = CH / RPI;          // row-loads per lane per tensor per tile
+  constexpr int TSA = tsa_of(NS);
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, nthreads = blockDim.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -77,14 +84,14 @@ __global__ __launch_bounds__(512) void scan_bwd_kernel(const BwdParams p) {
 
   const int nwaves = nthreads >> 6;
   float* sBC = smem;                                   // [2 buf][2][16][TS]   B, C tiles
-  float* sAcc = smem + 2 * 2 * kNState * TS;           // [2 buf][nwaves][2][16][TS]   dB, dC partial sums, one slab per wave
-  float* wl = smem + (2 + 2 * nwaves) * 2 * kNState * TS + wave * (3 * CH * TS);
+  float* sAcc = smem + 2 * 2 * kNState * TS;           // [2 buf][nwaves][2][16][TSA]   dB, dC partial sums, one slab per wave
+  float* wl = smem + 2 * 2 * kNState * TS + 2 * nwaves * 2 * kNState * TSA + wave * (3 * CH * TS);
   float* s_u = wl;                                     // u      -> du   (in place)
   float* s_dl = wl + CH * TS;                          // delta'
   float* s_g = wl + 2 * CH * TS;                       // dout -> d(delta') (in place)
 
   // ---- recurrence identity
-  const int g = lane >> 4, c = lane & 15;
+  const int g = lane / CH, c = lane % CH;
   const int hc = cw * p.CW + wave * CH + c;
   const bool cvalid = hc < p.H;
   const int d = grp * p.H + (cvalid ? hc : 0);
@@ -98,10 +105,11 @@ __global__ __launch_bounds__(512) void scan_bwd_kernel(const BwdParams p) {
   }
   const float Dc = p.D ? p.D[d] : 0.f;
   const float* chk_base = p.x_chk + ((int64_t)b * p.dim + d) * p.nchk * kNState + g * NS;
-  // which of the 8 reduced dB/dC sums this lane ends up with (butterfly below): idx = 4*bit2 + 2*bit3 + bit0
-  // (the lanes with bit1 set hold duplicates and stay out of the LDS atomic)
-  const int ridx = ((c >> 2) & 1) * 4 + ((c >> 3) & 1) * 2 + (c & 1);
-  float* acc_lane = sAcc + ((wave * 2 + (ridx >> 2)) * kNState + g * NS + (ridx & 3)) * TS;   // + buf*nwaves*2*16*TS + t
+  // which of the 2*NS reduced dB/dC sums this lane ends up with (butterfly below).  NS = 4: idx = 4*bit2 + 2*bit3 + bit0 (the
+  // lanes with bit1 set hold duplicates and stay out of the store); NS = 2: idx = 2*bit2 + bit1 (duplicates: bit0 set)
+  const int ridx = NS == 4 ? ((c >> 2) & 1) * 4 + ((c >> 3) & 1) * 2 + (c & 1) : ((c >> 2) & 1) * 2 + ((c >> 1) & 1);
+  const bool acc_writer = NS == 4 ? !(c & 2) : !(c & 1);
+  float* acc_lane = sAcc + ((wave * 2 + ridx / NS) * kNState + g * NS + ridx % NS) * TSA;   // + buf*nwaves*2*16*TSA + t
 
   // ---- staging identity: lane -> (row r of an 8-row group, float4 column q)
   const int r = lane / QL, q = lane % QL;
@@ -176,9 +184,9 @@ __global__ __launch_bounds__(512) void scan_bwd_kernel(const BwdParams p) {
     // carried 4 useful dwords (PMC: the dB/dC atomics cost 4x their bytes in WRITE_SIZE, profiles/r2_scan_traffic_pmc.txt).
     for (int idx = tid; idx < 2 * kNState * T; idx += nthreads) {
       const int which = idx / (kNState * T), n = (idx / T) % kNState, tt = idx % T;
-      const float* a = sAcc + ((buf * nwaves * 2 + which) * kNState + n) * TS + tt;
+      const float* a = sAcc + ((buf * nwaves * 2 + which) * kNState + n) * TSA + tt;
       float v = a[0];
-      for (int w = 1; w < nwaves; ++w) v += a[w * 2 * kNState * TS];
+      for (int w = 1; w < nwaves; ++w) v += a[w * 2 * kNState * TSA];
       const int te = t0 + tt;
       if (te < p.L) {
         float* pdst = (which ? dCbase + n * p.dC_sn : dBbase + n * p.dB_sn) + (rev ? p.L - 1 - te : te);
@@ -193,11 +201,20 @@ __global__ __launch_bounds__(512) void scan_bwd_kernel(const BwdParams p) {
   issue_loads((p.ntiles - 1) * T);
   // checkpoint prefetch for the first sub-tile to be processed (the state BEFORE sub-tile `sub` of `tile`)
   auto chk_index = [&](int tile, int sub) { return tile * NSUB + sub - 1; };
-  float4 x0n = make_float4(0.f, 0.f, 0.f, 0.f);
+  float x0n[NS];
+  auto load_chk = [&](int64_t ci, bool ok) {      // NS consecutive states of the checkpoint: one 16-B or 8-B load
+    if constexpr (NS == 4) {
+      const float4 v = ok ? *reinterpret_cast<const float4*>(chk_base + ci * kNState) : make_float4(0.f, 0.f, 0.f, 0.f);
+      x0n[0] = v.x; x0n[1] = v.y; x0n[2] = v.z; x0n[3] = v.w;
+    } else {
+      const float2 v = ok ? *reinterpret_cast<const float2*>(chk_base + ci * kNState) : make_float2(0.f, 0.f);
+      x0n[0] = v.x; x0n[1] = v.y;
+    }
+  };
   {
     const int tl0 = min(T, p.L - (p.ntiles - 1) * T);
     const int ci = chk_index(p.ntiles - 1, (tl0 + kChunk - 1) / kChunk - 1);
-    if (ci >= 0 && cvalid) x0n = *reinterpret_cast<const float4*>(chk_base + (int64_t)ci * kNState);
+    load_chk(ci, ci >= 0 && cvalid);
   }
 
   for (int tile = p.ntiles - 1; tile >= 0; --tile) {
@@ -242,7 +259,7 @@ __global__ __launch_bounds__(512) void scan_bwd_kernel(const BwdParams p) {
     const int nsub = (tlen + kChunk - 1) / kChunk;
     const float* sB = sBC + ((buf * 2 + 0) * kNState + g * NS) * TS;
     const float* sC = sBC + ((buf * 2 + 1) * kNState + g * NS) * TS;
-    float* accb = acc_lane + buf * nwaves * 2 * kNState * TS;
+    float* accb = acc_lane + buf * nwaves * 2 * kNState * TSA;
     auto phase2 = [&](auto rvtag) {
     constexpr bool RV = decltype(rvtag)::value;
     auto colof = [](int to) { return RV ? T - 4 - to : to; };                  // LDS column (floats) of time offset `to`
@@ -253,13 +270,14 @@ __global__ __launch_bounds__(512) void scan_bwd_kernel(const BwdParams p) {
       // multiple of 16 is partly padding: L = 196 -> 4 of 16 steps, L = 49 -> 1 of 16); the others are skipped entirely
       const int ntq = (min(kChunk, p.L - (t0 + ts)) + 3) >> 2;
       float xs[kChunk][NS];
-      const float x0[NS] = {x0n.x, x0n.y, x0n.z, x0n.w};
+      float x0[NS];
+#pragma unroll
+      for (int j = 0; j < NS; ++j) x0[j] = x0n[j];
       {   // prefetch the checkpoint of the NEXT sub-tile to be processed
         int nt = tile, ns_ = sub - 1;
         if (ns_ < 0) { nt = tile - 1; ns_ = NSUB - 1; }
         const int ci = chk_index(nt, ns_);
-        x0n = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (nt >= 0 && ci >= 0 && cvalid) x0n = *reinterpret_cast<const float4*>(chk_base + (int64_t)ci * kNState);
+        load_chk(ci, nt >= 0 && ci >= 0 && cvalid);
       }
       // forward recompute of the 16 states
 #pragma unroll
@@ -303,7 +321,7 @@ __global__ __launch_bounds__(512) void scan_bwd_kernel(const BwdParams p) {
           const float dl = at(dl4, e), ut = at(u4, e), gt = at(g4, e);
           const float dlu = dl * ut;
           float s1 = 0.f, s2 = 0.f;
-          float v[8];                                  // dB partials [0..3], dC partials [4..7]
+          float v[2 * NS];                             // dB partials [0..NS-1], dC partials [NS..2*NS-1]
 #pragma unroll
           for (int j = 0; j < NS; ++j) {
             const float Bn = at(Bv[j], e), Cn = at(Cv[j], e);
@@ -314,7 +332,7 @@ __global__ __launch_bounds__(512) void scan_bwd_kernel(const BwdParams p) {
             dAacc[j] = fmaf(t2, dl, dAacc[j]);
             s1 = fmaf(t2, An[j], s1);
             s2 = fmaf(gxt, Bn, s2);
-            v[4 + j] = gt * xc;
+            v[NS + j] = gt * xc;
             v[j] = gxt * dlu;
             gx[j] = __builtin_amdgcn_exp2f(dl * A2[j]) * gxt;   // a_t recomputed: keeping 64 more VGPRs would spill
           }
@@ -328,11 +346,14 @@ __global__ __launch_bounds__(512) void scan_bwd_kernel(const BwdParams p) {
             const auto r16 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, s), __builtin_bit_cast(unsigned, s), false, false);
             const unsigned q0 = r16[0], q1 = r16[1];
             pa = __builtin_bit_cast(float, q0) + __builtin_bit_cast(float, q1);   // rows 0,1: ddelta'   rows 2,3: du - D*g
+            if constexpr (NS == 2) pa += dpp_f<DPP_ROW_ROR8>(pa);                   // 8 state groups: the two of a 16-lane row
           }
           (&ddl4.x)[RV ? 3 - e : e] = pa;      // d(delta'); the softplus derivative is applied once per element in phase 3
           (&du4.x)[RV ? 3 - e : e] = fmaf(Dc, gt, pa);
-          // dB/dC: 8 values x 16 lanes -> one value per lane (halving butterfly), then one LDS atomic per lane
+          // dB/dC: 2*NS values x CH lanes -> one value per lane (halving butterfly), then one plain store per lane into the slab
           {
+            float w1;
+            if constexpr (NS == 4) {
             // levels 1 and 2 (8 -> 4 -> 2 values) pair lanes that sit in different DPP banks (bit 2: i <-> i^7 by
             // row_half_mirror; bit 3: i <-> i^8 by row_ror:8), so "keep one half, add the partner's copy of it" is ONE
             // bank-masked v_add_f32_dpp per kept value and bank set — no v_cndmask.  Hand-written: the compiler cannot
@@ -355,13 +376,27 @@ __global__ __launch_bounds__(512) void scan_bwd_kernel(const BwdParams p) {
                 : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3])
                 : "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]));
             const bool b0 = c & 1;
-            float w1 = dpp_add<DPP_QUAD_XOR1>(b0 ? v[1] : v[0], b0 ? v[0] : v[1]);   // pair i <-> i^1; bit0 decides
+            w1 = dpp_add<DPP_QUAD_XOR1>(b0 ? v[1] : v[0], b0 ? v[0] : v[1]);   // pair i <-> i^1; bit0 decides
             w1 += dpp_f<DPP_QUAD_XOR2>(w1);           // pair i <-> i^2 (both lanes end with the full sum)
-            if (!(c & 2)) accb[to + e] = w1;       // this wave's own slab: a plain ds_write_b32
+            } else {
+              // 4 values x 8 lanes.  Level 1 pairs c <-> 7-c (row_half_mirror inside each 8-lane half row); the lanes c < 4
+              // sit in DPP banks 0 / 2, c >= 4 in banks 1 / 3, so one bank-masked add per kept value: c < 4 keeps dB, c >= 4 dC
+              asm("s_nop 1\n\t"
+                  "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+                  "v_add_f32_dpp %0, %2, %2 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+                  "v_add_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+                  "v_add_f32_dpp %1, %3, %3 row_half_mirror row_mask:0xf bank_mask:0xa"
+                  : "+v"(v[0]), "+v"(v[1])
+                  : "v"(v[2]), "v"(v[3]));
+              const bool b1 = c & 2;
+              w1 = dpp_add<DPP_QUAD_XOR2>(b1 ? v[1] : v[0], b1 ? v[0] : v[1]);   // pair i <-> i^2; bit1 decides the state
+              w1 += dpp_f<DPP_QUAD_XOR1>(w1);          // pair i <-> i^1 (both lanes end with the full sum)
+            }
+            if (acc_writer) accb[to + e] = w1;     // this wave's own slab: a plain ds_write_b32
           }
         }
         if (g == 0) *reinterpret_cast<float4*>(s_g + c * TS + colof(to)) = ddl4;   // over the consumed dout quad; delta' stays
-        if (g == 2) *reinterpret_cast<float4*>(s_u + c * TS + colof(to)) = du4;
+        if (g == NG / 2) *reinterpret_cast<float4*>(s_u + c * TS + colof(to)) = du4;
       }
     }
     };   // phase2
@@ -416,12 +451,18 @@ __global__ __launch_bounds__(512) void scan_bwd_kernel(const BwdParams p) {
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-template <bool VEC, bool SP>
+template <int NS, bool VEC, bool SP>
 int launch(const BwdParams& p, int nblocks, int waves, hipStream_t stream) {
-  const size_t lds = sizeof(float) * ((2 + 2 * (size_t)waves) * 2 * kNState * TS + (size_t)waves * 3 * CH * TS);
-  if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)scan_bwd_kernel<VEC, SP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((scan_bwd_kernel<VEC, SP>), dim3(nblocks), dim3(waves * 64), lds, stream, p);
+  const size_t lds = sizeof(float) * (2 * 2 * kNState * TS + 2 * (size_t)waves * 2 * kNState * tsa_of(NS) + (size_t)waves * 3 * ch_of(NS) * TS);
+  if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)scan_bwd_kernel<NS, VEC, SP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((scan_bwd_kernel<NS, VEC, SP>), dim3(nblocks), dim3(waves * 64), lds, stream, p);
   return (int)hipGetLastError();
+}
+
+template <int NS>
+int launch_ns(const BwdParams& p, int nblocks, int waves, bool vec, bool sp, hipStream_t stream) {
+  if (vec) return sp ? launch<NS, true, true>(p, nblocks, waves, stream) : launch<NS, true, false>(p, nblocks, waves, stream);
+  return sp ? launch<NS, false, true>(p, nblocks, waves, stream) : launch<NS, false, false>(p, nblocks, waves, stream);
 }
 }  // namespace
 
@@ -457,17 +498,29 @@ int scan_bwd_launch(const mm_scan_args* a, hipStream_t stream) {
   if (p.dB_sn > snmax) snmax = p.dB_sn;
   if (p.dC_sn > snmax) snmax = p.dC_sn;
   if (span >= 0x7ffffff0ll || (int64_t)kNState * snmax * 4 >= 0x7ffffff0ll) return MM_ERR_UNSUPPORTED;
+  // states per lane: 2 when 4 would leave the chip below 2 waves per SIMD (the 56x56 stage of T/S at <= 64 images, the 96x96
+  // stage of B at 32) — half-width waves, twice as many, 3 per SIMD by their registers.  variant bit 24 / 25 force 2 / 4.
+  // Measured (tools/bench_scan.py, ms, 2 vs 4 states per lane): S Bz=64 56x56 1.25 / 1.42, S Bz=32 56x56 0.93 / 1.07, B Bz=32
+  // 96x96 2.72 / 2.98; directions wider than 128 channels need three or more workgroups each way and lose (S Bz=32 28x28:
+  // 0.48 / 0.38).
+  const long waves4 = (long)a->batch * a->G * ((p.H + 15) / 16);
+  int ns = (waves4 < 2048 && p.H <= 128) ? 2 : 4;
+  if (a->variant & (1 << 24)) ns = 2;
+  if (a->variant & (1 << 25)) ns = 4;
+  const int CH = ch_of(ns);
   const int waves_needed = (p.H + CH - 1) / CH;
-  // waves per workgroup (<= 8: register budget).  A direction that fits ONE workgroup (<= 128 channels) gets one when there are
-  // enough (batch, direction) pairs for every CU: dB/dC then leave with plain stores (measured, S/Bz=64 stage 1: 1.51 ms
-  // with 256 x 6 waves vs 1.58-1.65 ms with 512 x 3 waves + atomics).  Otherwise 4-wave workgroups — the price is fp32 atomics on dB/dC from the workgroups that share a
-  // direction (measured: 4-wave workgroups beat 6- and 8-wave ones at stages 2-4: 0.62 vs 0.76 / 0.80 ms, 0.32 vs 0.34 ms)
+  // waves per workgroup (<= 8 at 4 states per lane, <= 12 at 2: register budget).  A direction that fits ONE workgroup gets one
+  // when there are enough (batch, direction) pairs for every CU: dB/dC then leave with plain stores (measured, S/Bz=64 stage
+  // 1: 1.51 ms with 256 x 6 waves vs 1.58-1.65 ms with 512 x 3 waves + atomics).  Otherwise 4-wave workgroups — the price is
+  // fp32 atomics on dB/dC from the workgroups that share a direction (measured: 4-wave workgroups beat 6- and 8-wave ones at
+  // stages 2-4: 0.62 vs 0.76 / 0.80 ms, 0.32 vs 0.34 ms)
+  const int wmax = ns == 4 ? 8 : 12;
   int maxw;
   const int forced = (a->variant >> 16) & 0xff;              // tuning override
-  if (forced > 0) maxw = forced > 8 ? 8 : forced;
-  else if (waves_needed <= 8 && (long)a->batch * a->G >= 256) maxw = 8;
-  else maxw = 4;   // never fewer: 2-wave workgroups double the atomics and lost everywhere they were measured (B, Bz = 32,
-                   // 96x96 stage: 4.87 ms with 512 x 2 waves, 3.24 ms with 256 x 4, 4.25 ms with 128 x 8)
+  if (forced > 0) maxw = forced > wmax ? wmax : forced;
+  else if (waves_needed <= wmax && (long)a->batch * a->G >= 256) maxw = wmax;
+  else maxw = ns == 4 ? 4 : 8;   // never fewer: 2-wave workgroups double the atomics and lost everywhere they were measured (B, Bz = 32,
+                                 // 96x96 stage at 4 states per lane: 4.87 ms with 512 x 2 waves, 3.24 ms with 256 x 4, 4.25 ms with 128 x 8)
   const int ncw0 = (waves_needed + maxw - 1) / maxw;
   const int waves = (waves_needed + ncw0 - 1) / ncw0;
   p.CW = waves * CH;
@@ -479,8 +532,7 @@ int scan_bwd_launch(const mm_scan_args* a, hipStream_t stream) {
                    a->B_sg % 4 == 0 && a->B_sn % 4 == 0 && a->C_sb % 4 == 0 && a->C_sg % 4 == 0 && a->C_sn % 4 == 0 &&
                    p.o_sd % 4 == 0 && p.g_sb % 4 == 0 && p.o_sb % 4 == 0;
   const bool sp = a->delta_softplus != 0;
-  if (vec) return sp ? launch<true, true>(p, nblocks, waves, stream) : launch<true, false>(p, nblocks, waves, stream);
-  return sp ? launch<false, true>(p, nblocks, waves, stream) : launch<false, false>(p, nblocks, waves, stream);
+  return ns == 4 ? launch_ns<4>(p, nblocks, waves, vec, sp, stream) : launch_ns<2>(p, nblocks, waves, vec, sp, stream);
 }
 
 }  // namespace mm

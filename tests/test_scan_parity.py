@@ -148,11 +148,20 @@ def test_forward_options():
 
 @pytest.mark.parametrize("shape", [(2, 4, 8, 37), (1, 4, 24, 196), (2, 4, 96, 64), (1, 2, 5, 130), (3, 4, 32, 49),
                                    (1, 4, 200, 80)])
-def test_backward_vs_oracle(shape):
+@pytest.mark.parametrize("bwd_variant", [0, 1 << 24, 1 << 25, (1 << 24) | (3 << 16), (1 << 24) | (12 << 16), (1 << 25) | (2 << 16)],
+                         ids=["plan", "2states", "4states", "2states_3waves", "2states_12waves", "4states_2waves"])
+def test_backward_vs_oracle(shape, bwd_variant, monkeypatch):
+    """Both lane mappings of scan_bwd.hip (2 and 4 states per lane: variant bits 24 / 25) and several workgroup widths
+    (variant bits 16-23: one workgroup per direction with plain dB/dC stores, or several with atomics)."""
+    from medmamba_amd import selective_scan_interface as ssi
+    monkeypatch.setattr(ssi, "_BWD_VARIANT", bwd_variant)
     _check_bwd(_make(*shape, seed=1 + sum(shape)))
 
 
-def test_backward_options():
+@pytest.mark.parametrize("bwd_variant", [1 << 24, 1 << 25])
+def test_backward_options(bwd_variant, monkeypatch):
+    from medmamba_amd import selective_scan_interface as ssi
+    monkeypatch.setattr(ssi, "_BWD_VARIANT", bwd_variant)
     u, delta, A, B, C, D, bias, dout = _make(2, 4, 16, 100, seed=8)
     _check_bwd((u, delta, A, B, C, None, bias, dout))
     _check_bwd((u, delta, A, B, C, D, None, dout))
@@ -228,6 +237,14 @@ def test_cross_scan_matches_explicit_flips_and_oracle():
     for name, t, w in zip(["du2", "ddelta", "dA", "dB", "dC", "dD", "dbias"], ins, wants):
         e = (t.grad.cpu().double() - w).abs().max().item() / max(1.0, w.abs().max().item())
         assert e <= BWD_RTOL, (name, e)
+
+
+@pytest.mark.parametrize("bwd_variant", [1 << 24, 1 << 25], ids=["2states", "4states"])
+def test_cross_scan_backward_in_both_lane_mappings(bwd_variant, monkeypatch):
+    """Reversed directions / shared u blocks (mirrored LDS tiles) through both lane mappings of the backward kernel."""
+    from medmamba_amd import selective_scan_interface as ssi
+    monkeypatch.setattr(ssi, "_BWD_VARIANT", bwd_variant)
+    test_cross_scan_matches_explicit_flips_and_oracle()
 
 
 @pytest.mark.parametrize("L", [49, 130])
@@ -313,6 +330,14 @@ def test_full_size_backward_properties(shape, monkeypatch):
     for name, a1, a3 in zip(["du", "ddelta", "dA", "dB", "dC", "dD", "dbias"], (du, ddelta, dA, dB, dC, dD, dbias), r3):
         scale = max(1.0, float(a1.abs().max()))
         assert float((a3 - a1).abs().max()) <= 2e-4 * scale, name
+    del r3
+    # (e) the other lane mapping (the plan takes 2 states per lane at stage 1, 4 at stage 3)
+    for force in (1 << 24, 1 << 25):
+        r4 = _run_bwd(args, cm, force, monkeypatch)
+        for name, a1, a4 in zip(["du", "ddelta", "dA", "dB", "dC", "dD", "dbias"], (du, ddelta, dA, dB, dC, dD, dbias), r4):
+            scale = max(1.0, float(a1.abs().max()))
+            assert float((a4 - a1).abs().max()) <= 2e-4 * scale, (name, force)
+        del r4
 
 
 @pytest.mark.parametrize("variant", [20, 24])
