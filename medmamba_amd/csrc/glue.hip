@@ -582,20 +582,177 @@ __global__ __launch_bounds__(256) void ln_gate_bwd1_kernel(const float* __restri
   for (int i = threadIdx.x; i < 2 * D; i += blockDim.x) ws[(int64_t)blockIdx.x * 2 * D + i] = sred[i];   // one row per workgroup
 }
 
+// ---- cooperative single-pass variants for wide channel counts: the D channels of a position are split over ALL lanes of the
+// workgroup that share it (64/PW in each of the NW waves), the statistics meet in LDS.  With 16 lanes per position inside ONE
+// wave (ln_gate_*1_kernel<4, ...>, the D > 128 plan so far) a wave-wide load touched only 4 consecutive positions = 16 B of each
+// channel row: 1.4-1.6 TB/s at the 14x14 stage.  Here PW = 16 positions are contiguous per channel (64-B runs) at the same
+// registers per lane (CPL = D / (NW * 64 / PW)).
+template <int PW, int NW, int CPL>
+__global__ __launch_bounds__(NW * 64) void ln_gate_fwdc_kernel(const float* __restrict__ m, int64_t m_sb, int64_t m_sd,
+                                                               const float* __restrict__ z, int64_t z_sb, int64_t z_sd,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               float eps, float* __restrict__ y, int64_t y_sb, int64_t y_sd,
+                                                               float* __restrict__ mu_out, float* __restrict__ rstd_out, int D,
+                                                               int L, int npos_blocks) {
+  constexpr int LPW = 64 / PW, TPP = LPW * NW;
+  __shared__ float sstat[2][NW][PW];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int b = blockIdx.x / npos_blocks, pb = blockIdx.x % npos_blocks;
+  const int pl = lane % PW, p = pb * PW + pl;
+  const int ck = wv * LPW + lane / PW;
+  const bool ok = p < L;
+  const float* mp = m + (int64_t)b * m_sb + p;
+  const float* zp = z + (int64_t)b * z_sb + p;
+  float mv[CPL], zv[CPL], s1 = 0.f;
+#pragma unroll
+  for (int k = 0; k < CPL; ++k) {
+    const int d = ck + k * TPP;
+    const bool in = ok && d < D;
+    mv[k] = in ? mp[d * m_sd] : 0.f;
+    zv[k] = in ? zp[d * z_sd] : 0.f;
+    s1 += mv[k];
+  }
+  s1 = pos_sum<PW>(s1);
+  if (lane < PW) sstat[0][wv][pl] = s1;
+  __syncthreads();
+  float mu = 0.f;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) mu += sstat[0][w][pl];
+  mu /= D;
+  float s2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < CPL; ++k) {
+    const float dv = (ck + k * TPP < D) ? mv[k] - mu : 0.f;
+    s2 = fmaf(dv, dv, s2);
+  }
+  s2 = pos_sum<PW>(s2);
+  if (lane < PW) sstat[1][wv][pl] = s2;
+  __syncthreads();
+  float var = 0.f;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) var += sstat[1][w][pl];
+  const float rstd = __builtin_amdgcn_rsqf(var / D + eps);
+  if (!ok) return;
+  if (ck == 0) {
+    mu_out[(int64_t)b * L + p] = mu;
+    rstd_out[(int64_t)b * L + p] = rstd;
+  }
+  float* yp = y + (int64_t)b * y_sb + p;
+#pragma unroll
+  for (int k = 0; k < CPL; ++k) {
+    const int d = ck + k * TPP;
+    if (d < D) {
+      const float n = (mv[k] - mu) * rstd * gamma[d] + beta[d];
+      yp[d * y_sd] = n * (zv[k] * sigmoid_f(zv[k]));
+    }
+  }
+}
+
+template <int PW, int NW, int CPL>
+__global__ __launch_bounds__(NW * 64) void ln_gate_bwdc_kernel(const float* __restrict__ dy, int64_t g_sb, int64_t g_sd,
+                                                               const float* __restrict__ m, int64_t m_sb, int64_t m_sd,
+                                                               const float* __restrict__ z, int64_t z_sb, int64_t z_sd,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               const float* __restrict__ mu_in, const float* __restrict__ rstd_in,
+                                                               float* __restrict__ dm, int64_t dm_sb, int64_t dm_sd,
+                                                               float* __restrict__ dz, int64_t dz_sb, int64_t dz_sd,
+                                                               float* __restrict__ ws, int D, int L, int npos_blocks) {
+  constexpr int LPW = 64 / PW, TPP = LPW * NW;
+  __shared__ float sstat[2][NW][PW];
+  extern __shared__ float sred[];                       // [2*D]: dgamma | dbeta of this workgroup
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int b = blockIdx.x / npos_blocks, pb = blockIdx.x % npos_blocks;
+  const int pl = lane % PW, p = pb * PW + pl;
+  const int ck = wv * LPW + lane / PW;
+  const bool ok = p < L;
+  const float* mp = m + (int64_t)b * m_sb + p;
+  const float* gp = dy + (int64_t)b * g_sb + p;
+  const float* zp = z + (int64_t)b * z_sb + p;
+  const float mu = ok ? mu_in[(int64_t)b * L + p] : 0.f, rstd = ok ? rstd_in[(int64_t)b * L + p] : 0.f;
+  for (int i = threadIdx.x; i < 2 * D; i += NW * 64) sred[i] = 0.f;
+  float gv[CPL], zv[CPL], xh[CPL], c1 = 0.f, c2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < CPL; ++k) {
+    const int d = ck + k * TPP;
+    const bool in = ok && d < D;
+    zv[k] = in ? zp[d * z_sd] : 0.f;
+    gv[k] = in ? gp[d * g_sd] : 0.f;
+    xh[k] = in ? (mp[d * m_sd] - mu) * rstd : 0.f;
+    const float dn = in ? gv[k] * (zv[k] * sigmoid_f(zv[k])) * gamma[d] : 0.f;
+    c1 += dn;
+    c2 = fmaf(dn, xh[k], c2);
+  }
+  c1 = pos_sum<PW>(c1);
+  c2 = pos_sum<PW>(c2);
+  if (lane < PW) { sstat[0][wv][pl] = c1; sstat[1][wv][pl] = c2; }
+  __syncthreads();                                       // also orders the zero-fill of sred before the atomics below
+  c1 = 0.f; c2 = 0.f;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) { c1 += sstat[0][w][pl]; c2 += sstat[1][w][pl]; }
+  c1 /= D; c2 /= D;
+  float* dmp = dm + (int64_t)b * dm_sb + p;
+  float* dzp = dz + (int64_t)b * dz_sb + p;
+#pragma unroll
+  for (int k = 0; k < CPL; ++k) {
+    const int d = ck + k * TPP;
+    float pg = 0.f, pb_ = 0.f;
+    if (ok && d < D) {
+      const float zz = zv[k], s_ = sigmoid_f(zz), sz = zz * s_;
+      const float gm = gamma[d];
+      const float n = xh[k] * gm + beta[d];
+      const float dn = gv[k] * sz;
+      dzp[d * dz_sd] = gv[k] * n * (s_ * (1.f + zz * (1.f - s_)));
+      dmp[d * dm_sd] = rstd * (dn * gm - c1 - xh[k] * c2);
+      pg = dn * xh[k];
+      pb_ = dn;
+    }
+    // sum over the PW positions of this wave that share channel d (lanes with equal lane / PW): xor over the low bits
+#pragma unroll
+    for (int s_ = 1; s_ < PW; s_ <<= 1) {
+      pg += __shfl_xor(pg, s_);
+      pb_ += __shfl_xor(pb_, s_);
+    }
+    if (pl == 0 && d < D) {          // every channel belongs to exactly one (wave, lane group): plain stores would do, too
+      sred[d] = pg;
+      sred[D + d] = pb_;
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * D; i += NW * 64) ws[(int64_t)blockIdx.x * 2 * D + i] = sred[i];   // one row per workgroup
+}
+
 // plan of the LayerNorm + gate kernels: positions per wave and, for the single-pass kernels, channels per lane
-// (cpl = 0: D is too wide for the register-resident form -> two-pass kernels)
-struct LnPlan { int pw, cpl; };
+// (cpl = 0: D is too wide for the register-resident form -> two-pass kernels; nw > 0: cooperative kernel with nw waves)
+struct LnPlan { int pw, cpl, nw, ppb; };     // ppb = positions per workgroup
 inline LnPlan plan_ln(int batch, int D, int L, bool bwd) {
-  const int tpp = D <= 128 ? 4 : 16;
-  const int need = (D + tpp - 1) / tpp;
   LnPlan pl;
   // the backward keeps three values per channel: 48 channels per lane would be 256 VGPRs (1 wave per SIMD)
   static const int two_pass = [] { const char* e = getenv("MM_LN_TWO_PASS"); return e ? atoi(e) : 0; }();   // tuning knob: 1 = fwd, 2 = bwd, 3 = both
+  static const int coop = [] { const char* e = getenv("MM_LN_COOP"); return e ? atoi(e) : 1; }();          // 0: never the cooperative kernels
+  if (D > 128 && coop && !(two_pass & (bwd ? 2 : 1))) {
+    // 16 positions per workgroup (64-B runs per channel row); lanes per position: 16 (4 waves) or 32 (8 waves), the fewest
+    // that keep the channels of a lane within 32 (forward: two values per channel) / 24 (backward: three)
+    const int cap = bwd ? 24 : 32;
+    const int lpp = (D + 15) / 16 <= cap ? 16 : 32;
+    const int need = (D + lpp - 1) / lpp;
+    if (need <= cap) {
+      // forward with 16 lanes per position: 32 positions per workgroup (128-B runs, 8 waves) — measured (tools/bench_ln_gate.py,
+      // B = 64, us): D = 192 31.6 -> 28.0, D = 384 24.8 -> 20.3; the backward does not gain (61.4 -> 64.9, 55.8 -> 53.9)
+      static const int pw32 = [] { const char* e = getenv("MM_LN_PW32"); return e ? atoi(e) : 1; }();
+      const bool wide = pw32 && lpp == 16 && !bwd;
+      pl.pw = wide ? 32 : 16; pl.nw = wide ? 8 : lpp / 4; pl.ppb = pl.pw;
+      pl.cpl = need <= 16 ? 16 : need <= 24 ? 24 : need <= 32 ? 32 : 48;
+      return pl;
+    }
+  }
+  const int tpp = D <= 128 ? 4 : 16;
+  const int need = (D + tpp - 1) / tpp;
   // measured (tools/bench_ln_gate.py, B = 64): forward 86 -> 48 / 39 -> 36 / 40 -> 31 / 38 -> 27 us for the four S stages;
   // backward only wins where 16 lanes share a position and still own <= 24 channels (D = 384: 80 -> 55 us) — with 4
   // lanes per position it writes 4x the partial-sum rows (165 -> 158 us at D = 96, 60 -> 70 us at D = 192)
   static const int bwd_all = [] { const char* e = getenv("MM_LN_BWD1_ALL"); return e ? atoi(e) : 0; }();
   const bool fits = bwd ? ((bwd_all ? true : (tpp == 16 && need > 16)) && need <= 24) : need <= 48;
+  pl.nw = 0;
   if (fits && !(two_pass & (bwd ? 2 : 1))) {
     pl.pw = 64 / tpp;
     pl.cpl = need <= 8 ? 8 : need <= 16 ? 16 : need <= 24 ? 24 : need <= 32 ? 32 : 48;
@@ -603,8 +760,60 @@ inline LnPlan plan_ln(int batch, int D, int L, bool bwd) {
     pl.pw = pick_pw(batch, L);
     pl.cpl = 0;
   }
+  pl.ppb = 4 * pl.pw;
   return pl;
 }
+
+#define MM_LN_ARGS_F m, m_sb, m_sd, z, z_sb, z_sd, gamma, beta, eps, y, y_sb, y_sd, mu, rstd, D, L, npb
+int launch_ln_fwdc(const LnPlan& pl, dim3 grid, hipStream_t s, const float* m, int64_t m_sb, int64_t m_sd, const float* z,
+                   int64_t z_sb, int64_t z_sd, const float* gamma, const float* beta, float eps, float* y, int64_t y_sb, int64_t y_sd,
+                   float* mu, float* rstd, int D, int L, int npb) {
+#define MM_LN_FWDC(NW_, CPL_) hipLaunchKernelGGL((ln_gate_fwdc_kernel<16, NW_, CPL_>), grid, dim3(NW_ * 64), 0, s, MM_LN_ARGS_F)
+#define MM_LN_FWDC32(CPL_) hipLaunchKernelGGL((ln_gate_fwdc_kernel<32, 8, CPL_>), grid, dim3(512), 0, s, MM_LN_ARGS_F)
+  if (pl.pw == 32) {
+    switch (pl.cpl) {
+      case 16: MM_LN_FWDC32(16); break;
+      case 24: MM_LN_FWDC32(24); break;
+      default: MM_LN_FWDC32(32); break;
+    }
+  } else if (pl.nw == 4) {
+    switch (pl.cpl) {
+      case 16: MM_LN_FWDC(4, 16); break;
+      case 24: MM_LN_FWDC(4, 24); break;
+      case 32: MM_LN_FWDC(4, 32); break;
+      default: MM_LN_FWDC(4, 48); break;
+    }
+  } else {
+    switch (pl.cpl) {
+      case 16: MM_LN_FWDC(8, 16); break;
+      case 24: MM_LN_FWDC(8, 24); break;
+      case 32: MM_LN_FWDC(8, 32); break;
+      default: MM_LN_FWDC(8, 48); break;
+    }
+  }
+#undef MM_LN_FWDC
+  return (int)hipGetLastError();
+}
+#undef MM_LN_ARGS_F
+
+#define MM_LN_ARGS_B dy, dy_sb, dy_sd, m, m_sb, m_sd, z, z_sb, z_sd, gamma, beta, mu, rstd, dm, dm_sb, dm_sd, dz, dz_sb, dz_sd, ws, D, L, npb
+int launch_ln_bwdc(const LnPlan& pl, dim3 grid, hipStream_t s, const float* dy, int64_t dy_sb, int64_t dy_sd, const float* m,
+                   int64_t m_sb, int64_t m_sd, const float* z, int64_t z_sb, int64_t z_sd, const float* gamma, const float* beta,
+                   const float* mu, const float* rstd, float* dm, int64_t dm_sb, int64_t dm_sd, float* dz, int64_t dz_sb,
+                   int64_t dz_sd, float* ws, int D, int L, int npb) {
+#define MM_LN_BWDC(NW_, CPL_) hipLaunchKernelGGL((ln_gate_bwdc_kernel<16, NW_, CPL_>), grid, dim3(NW_ * 64), 2 * D * sizeof(float), s, MM_LN_ARGS_B)
+#define MM_LN_BWDC32(CPL_) hipLaunchKernelGGL((ln_gate_bwdc_kernel<32, 8, CPL_>), grid, dim3(512), 2 * D * sizeof(float), s, MM_LN_ARGS_B)
+  if (pl.pw == 32) {
+    if (pl.cpl == 16) MM_LN_BWDC32(16); else MM_LN_BWDC32(24);
+  } else if (pl.nw == 4) {
+    if (pl.cpl == 16) MM_LN_BWDC(4, 16); else MM_LN_BWDC(4, 24);
+  } else {
+    if (pl.cpl == 16) MM_LN_BWDC(8, 16); else MM_LN_BWDC(8, 24);
+  }
+#undef MM_LN_BWDC
+  return (int)hipGetLastError();
+}
+#undef MM_LN_ARGS_B
 
 template <int PW>
 int launch_ln_fwd1(int cpl, dim3 grid, hipStream_t s, const float* m, int64_t m_sb, int64_t m_sd, const float* z, int64_t z_sb,
@@ -694,8 +903,8 @@ int mm_plane_transpose(const float* src, int64_t src_sb, int64_t src_sd, float* 
 }
 
 int mm_ln_gate_rows(int batch, int D, int L) {   // rows of the dgamma/dbeta workspace written by mm_ln_gate_bwd
-  const int pw = plan_ln(batch, D, L, true).pw;
-  return batch * ((L + 4 * pw - 1) / (4 * pw));
+  const int ppb = plan_ln(batch, D, L, true).ppb;
+  return batch * ((L + ppb - 1) / ppb);
 }
 
 int mm_ln_gate_fwd(const float* m, int64_t m_sb, int64_t m_sd, const float* z, int64_t z_sb, int64_t z_sd, const float* gamma,
@@ -704,9 +913,10 @@ int mm_ln_gate_fwd(const float* m, int64_t m_sb, int64_t m_sd, const float* z, i
   if (!m || !z || !gamma || !beta || !y || !mu || !rstd) return MM_ERR_NULL;
   if (batch <= 0 || D <= 0 || L <= 0) return MM_ERR_SHAPE;
   const LnPlan pl = plan_ln(batch, D, L, false);
-  const int pw = pl.pw, npb = (L + 4 * pw - 1) / (4 * pw);
+  const int pw = pl.pw, npb = (L + pl.ppb - 1) / pl.ppb;
   const dim3 grid(batch * npb), blk(256);
   hipStream_t s = (hipStream_t)stream;
+  if (pl.nw > 0) return launch_ln_fwdc(pl, grid, s, m, m_sb, m_sd, z, z_sb, z_sd, gamma, beta, eps, y, y_sb, y_sd, mu, rstd, D, L, npb);
   if (pl.cpl > 0) {
     return pw == 16 ? launch_ln_fwd1<16>(pl.cpl, grid, s, m, m_sb, m_sd, z, z_sb, z_sd, gamma, beta, eps, y, y_sb, y_sd, mu, rstd, D, L, npb)
                     : launch_ln_fwd1<4>(pl.cpl, grid, s, m, m_sb, m_sd, z, z_sb, z_sd, gamma, beta, eps, y, y_sb, y_sd, mu, rstd, D, L, npb);
@@ -724,9 +934,11 @@ int mm_ln_gate_bwd(const float* dy, int64_t dy_sb, int64_t dy_sd, const float* m
   if (!dy || !m || !z || !gamma || !beta || !mu || !rstd || !dm || !dz || !ws) return MM_ERR_NULL;
   if (batch <= 0 || D <= 0 || L <= 0) return MM_ERR_SHAPE;
   const LnPlan pl = plan_ln(batch, D, L, true);
-  const int pw = pl.pw, npb = (L + 4 * pw - 1) / (4 * pw);
+  const int pw = pl.pw, npb = (L + pl.ppb - 1) / pl.ppb;
   const dim3 grid(batch * npb), blk(256);
   hipStream_t s = (hipStream_t)stream;
+  if (pl.nw > 0)
+    return launch_ln_bwdc(pl, grid, s, dy, dy_sb, dy_sd, m, m_sb, m_sd, z, z_sb, z_sd, gamma, beta, mu, rstd, dm, dm_sb, dm_sd, dz, dz_sb, dz_sd, ws, D, L, npb);
   if (pl.cpl > 0) {
     return pw == 16 ? launch_ln_bwd1<16>(pl.cpl, grid, s, dy, dy_sb, dy_sd, m, m_sb, m_sd, z, z_sb, z_sd, gamma, beta, mu, rstd, dm, dm_sb, dm_sd, dz, dz_sb, dz_sd, ws, D, L, npb)
                     : launch_ln_bwd1<4>(pl.cpl, grid, s, dy, dy_sb, dy_sd, m, m_sb, m_sd, z, z_sb, z_sd, gamma, beta, mu, rstd, dm, dm_sb, dm_sd, dz, dz_sb, dz_sd, ws, D, L, npb);

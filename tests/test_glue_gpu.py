@@ -323,6 +323,40 @@ def test_patch_merge_ln_model_widths():
             assert float((p.grad - q.grad).abs().max()) <= 5e-5 * max(1.0, float(q.grad.abs().max())), (C, name)
 
 
+@pytest.mark.parametrize("cm", [False, True], ids=["bm", "cm"])
+@pytest.mark.parametrize("shape", [(2, 192, 784), (3, 384, 196), (2, 768, 49), (2, 1024, 37), (1, 200, 50), (2, 520, 16), (1, 136, 3),
+                                   (2, 96, 100), (1, 1500, 20)])
+def test_ln_gate_kernels_all_plans(shape, cm):
+    """mm_ln_gate_fwd / _bwd (out_norm LayerNorm over channels + SiLU(z) gate on channel-first planes, MedMamba.py:300-301)
+    through every plan of glue.hip: one wave per position group (D <= 128), the cooperative kernels (4 / 8 waves share a
+    position: the model widths 192 ... 1024 and widths between them), the two-pass fallback (D = 1500; the backward at 1024)
+    — against torch's layer_norm + autograd, position counts that do not fill the 16-position tiles included."""
+    from medmamba_amd import _lib, ops
+    B, D, L = shape
+    lib = _lib.lib()
+    g = torch.Generator(device=DEV).manual_seed(D + L)
+    pl = lambda d=D: ops._planes(B, d, L, DEV, cm).normal_(generator=g)
+    m, z, dy = pl(), pl(), pl()
+    gamma = 1 + 0.1 * torch.randn(D, device=DEV, generator=g); beta = 0.1 * torch.randn(D, device=DEV, generator=g)
+    y, dm, dz = ops._planes(B, D, L, DEV, cm), ops._planes(B, D, L, DEV, cm), ops._planes(B, D, L, DEV, cm)
+    mu, rstd = torch.empty(B, L, device=DEV), torch.empty(B, L, device=DEV)
+    ws = torch.full((lib.mm_ln_gate_rows(B, D, L), 2 * D), float("nan"), device=DEV)
+    P, st = ops._pl, _lib.raw_stream()
+    _lib.check(lib.mm_ln_gate_fwd(*P(m), *P(z), gamma.data_ptr(), beta.data_ptr(), 1e-5, *P(y), mu.data_ptr(), rstd.data_ptr(), B, D, L, st), "fwd")
+    _lib.check(lib.mm_ln_gate_bwd(*P(dy), *P(m), *P(z), gamma.data_ptr(), beta.data_ptr(), mu.data_ptr(), rstd.data_ptr(), *P(dm), *P(dz),
+                                  ws.data_ptr(), B, D, L, st), "bwd")
+    mr, zr, gr, br = (t.detach().clone().contiguous().requires_grad_() for t in (m, z, gamma, beta))
+    ref = torch.nn.functional.layer_norm(mr.transpose(1, 2), (D,), gr, br, 1e-5).transpose(1, 2) * torch.nn.functional.silu(zr)
+    ref.backward(dy.contiguous())
+    close = lambda a, b, tol: float((a - b).abs().max()) <= tol * max(1.0, float(b.abs().max()))
+    assert close(y, ref.detach(), 2e-5)
+    assert close(mu, mr.detach().mean(1), 1e-5)
+    assert close(dm, mr.grad, 5e-5) and close(dz, zr.grad, 5e-5)
+    s = ws.sum(0)
+    assert torch.isfinite(s).all()                      # every workspace row was written
+    assert close(s[:D], gr.grad, 1e-4) and close(s[D:], br.grad, 1e-4)
+
+
 def test_patch_embed_permute_layernorm_kernel():
     """PatchEmbed2D's permute + LayerNorm (MedMamba.py:70-76) as one kernel each way against the op chain: model widths (96, 128),
     widths that are not a multiple of 64, the 512 limit, plane sizes that are not a multiple of the 32-position tile; and the
