@@ -341,6 +341,73 @@ __global__ __launch_bounds__(256) void plane_transpose_kernel(const float* __res
   }
 }
 
+// ---- small planes (H*W <= 256: the 14x14 and 7x7 stages): one WAVEFRONT per plane, 4 planes per workgroup and iteration.  The
+// 32x32-tile kernels above spend a 256-thread workgroup on 196 or 49 elements (24,576 / 49,152 workgroups per call: 33 / 60 us
+// for the merge, 30 / 56 us for the transpose at B = 64).  Lane l owns elements l, l+64, l+128, l+192 of the plane; the
+// transposed operand goes through a 256-float LDS row of the wave.
+// MERGE: m[pl, h*W+w] = o0 + o1 (row-major planes) + (o2 + o3)[w*H+h];   else: dst[pl, w*H+h] = src[pl, h*W+w]
+template <bool MERGE>
+__global__ __launch_bounds__(256) void plane_small_kernel(const float* __restrict__ src, int64_t src_sb, int64_t src_sd,
+                                                          float* __restrict__ dst, int64_t dst_sb, int64_t dst_sd, int D, int H,
+                                                          int W, int nplanes) {
+  __shared__ float tile[4][256];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int L = H * W;
+  int tr[4];                                   // transposed index of element lane + 64 j
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int i = lane + 64 * j, h = i / W, w = i - h * W;
+    tr[j] = i < L ? w * H + h : 0;
+  }
+  const int per_iter = gridDim.x * 4;
+  const int niter = (nplanes + per_iter - 1) / per_iter;
+  for (int it = 0; it < niter; ++it) {
+    const int pl = it * per_iter + blockIdx.x * 4 + wv;
+    const bool okp = pl < nplanes;
+    const int b = okp ? pl / D : 0, d = okp ? pl % D : 0;
+    float* t = dst + (int64_t)b * dst_sb + (int64_t)d * dst_sd;
+    if constexpr (MERGE) {
+      const float* o0 = src + (((int64_t)b * 4 + 0) * D + d) * L;      // src = out4 (batch, 4, D, L) contiguous
+      const float* o1 = o0 + (int64_t)D * L;
+      const float* o2 = o1 + (int64_t)D * L;
+      const float* o3 = o2 + (int64_t)D * L;
+      float a[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int i = lane + 64 * j;
+        const bool in = okp && i < L;
+        tile[wv][i] = in ? o2[i] + o3[i] : 0.f;
+        a[j] = in ? o0[i] + o1[i] : 0.f;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int i = lane + 64 * j;
+        if (okp && i < L) t[i] = a[j] + tile[wv][tr[j]];
+      }
+    } else {
+      const float* sp = src + (int64_t)b * src_sb + (int64_t)d * src_sd;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int i = lane + 64 * j;
+        if (okp && i < L) tile[wv][tr[j]] = sp[i];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int i = lane + 64 * j;
+        if (okp && i < L) t[i] = tile[wv][i];
+      }
+    }
+    __syncthreads();                           // the tile is rewritten by the next iteration
+  }
+}
+
+inline int small_plane_grid(int nplanes) {     // 4 planes per workgroup and iteration, up to 8 iterations
+  const int b = (nplanes + 31) / 32;
+  return b < 1 ? 1 : b;
+}
+
 // ---- LayerNorm over channels (out_norm, MedMamba.py:300) + gate y*silu(z) (:301), channel-first ----------------
 // m, y: (batch, D, L) contiguous; z: planes with batch stride z_sb.  Thread layout: PW consecutive positions x TPP
 // channel chunks per wave (TPP = 64/PW lanes share a position and split D); statistics mu/rstd: (batch, L).
@@ -888,8 +955,12 @@ int mm_dwconv_silu_cross_bwd(const float* du2, int64_t du2_sb, int64_t du2_sd, c
 int mm_cross_merge_fwd(const float* out4, float* m, int64_t m_sb, int64_t m_sd, int batch, int D, int H, int W, void* stream) {
   if (!out4 || !m) return MM_ERR_NULL;
   if (batch <= 0 || D <= 0 || H <= 0 || W <= 0) return MM_ERR_SHAPE;
-  hipLaunchKernelGGL(cross_merge_fwd_kernel, dim3(((W + 31) / 32) * ((H + 31) / 32) * batch * D), dim3(256), 0, (hipStream_t)stream,
-                     out4, m, m_sb, m_sd, D, H, W);
+  if ((int64_t)H * W <= 256)
+    hipLaunchKernelGGL(plane_small_kernel<true>, dim3(small_plane_grid(batch * D)), dim3(256), 0, (hipStream_t)stream, out4, (int64_t)0,
+                       (int64_t)0, m, m_sb, m_sd, D, H, W, batch * D);
+  else
+    hipLaunchKernelGGL(cross_merge_fwd_kernel, dim3(((W + 31) / 32) * ((H + 31) / 32) * batch * D), dim3(256), 0, (hipStream_t)stream,
+                       out4, m, m_sb, m_sd, D, H, W);
   return (int)hipGetLastError();
 }
 
@@ -897,8 +968,12 @@ int mm_plane_transpose(const float* src, int64_t src_sb, int64_t src_sd, float* 
                        int D, int H, int W, void* stream) {
   if (!src || !dst) return MM_ERR_NULL;
   if (batch <= 0 || D <= 0 || H <= 0 || W <= 0) return MM_ERR_SHAPE;
-  hipLaunchKernelGGL(plane_transpose_kernel, dim3(((W + 31) / 32) * ((H + 31) / 32) * batch * D), dim3(256), 0, (hipStream_t)stream,
-                     src, src_sb, src_sd, dst, dst_sb, dst_sd, D, H, W);
+  if ((int64_t)H * W <= 256)
+    hipLaunchKernelGGL(plane_small_kernel<false>, dim3(small_plane_grid(batch * D)), dim3(256), 0, (hipStream_t)stream, src, src_sb,
+                       src_sd, dst, dst_sb, dst_sd, D, H, W, batch * D);
+  else
+    hipLaunchKernelGGL(plane_transpose_kernel, dim3(((W + 31) / 32) * ((H + 31) / 32) * batch * D), dim3(256), 0, (hipStream_t)stream,
+                       src, src_sb, src_sd, dst, dst_sb, dst_sd, D, H, W);
   return (int)hipGetLastError();
 }
 

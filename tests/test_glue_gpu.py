@@ -357,6 +357,30 @@ def test_ln_gate_kernels_all_plans(shape, cm):
     assert close(s[:D], gr.grad, 1e-4) and close(s[D:], br.grad, 1e-4)
 
 
+@pytest.mark.parametrize("cm", [False, True], ids=["bm", "cm"])
+@pytest.mark.parametrize("shape", [(64, 96, 14, 14), (3, 40, 7, 7), (2, 5, 16, 16), (2, 7, 5, 9), (1, 3, 1, 1), (2, 6, 1, 200), (3, 9, 37, 1),
+                                   (2, 4, 16, 17), (1, 8, 56, 56), (2, 3, 33, 40)])
+def test_cross_merge_and_plane_transpose_kernels(shape, cm):
+    """mm_cross_merge_fwd (MedMamba.py:282-286, 298: un-transpose the column-major pair, sum the four) and mm_plane_transpose,
+    bit-exact against torch indexing — the one-wavefront-per-plane kernels (H*W <= 256) and the 32x32-tile kernels."""
+    from medmamba_amd import _lib, ops
+    B, D, H, W = shape
+    L = H * W
+    lib, st, P = _lib.lib(), _lib.raw_stream(), ops._pl
+    g = torch.Generator(device=DEV).manual_seed(H * 100 + W)
+    out4 = torch.randn(B, 4, D, L, device=DEV, generator=g)
+    m = ops._planes(B, D, L, DEV, cm).fill_(float("nan"))
+    _lib.check(lib.mm_cross_merge_fwd(out4.data_ptr(), *P(m), B, D, H, W, st), "merge")
+    colmajor = (out4[:, 2] + out4[:, 3]).view(B, D, W, H).transpose(2, 3).reshape(B, D, L)
+    want = (out4[:, 0] + out4[:, 1]) + colmajor
+    assert torch.equal(m, want)
+    src = ops._planes(B, 2 * D, L, DEV, cm).normal_(generator=g)
+    before = src[:, :D].clone()
+    _lib.check(lib.mm_plane_transpose(*P(src), *P(src[:, D:]), B, D, H, W, st), "transpose")
+    assert torch.equal(src[:, D:], before.view(B, D, H, W).transpose(2, 3).reshape(B, D, L))
+    assert torch.equal(src[:, :D], before)
+
+
 def test_patch_embed_permute_layernorm_kernel():
     """PatchEmbed2D's permute + LayerNorm (MedMamba.py:70-76) as one kernel each way against the op chain: model widths (96, 128),
     widths that are not a multiple of 64, the 512 limit, plane sizes that are not a multiple of the 32-position tile; and the

@@ -31,5 +31,16 @@ for C, hw in [(96, 56), (192, 28), (384, 14), (768, 7)]:
     rows.append(("dwconv bwd", t(lambda: torch.autograd.grad(u2, x, gu, retain_graph=True)), 4 * unit))
     lft = r(B, dm, hw, hw); ssm = pl(dm); xin = r(B, hw, hw, C)
     rows.append(("shuffle_residual fwd", t(lambda: ops.shuffle_residual(lft, ssm, xin, True)), 2 * unit))
+    from medmamba_amd import _lib
+    lib, st, P = _lib.lib(), _lib.raw_stream(), ops._pl
+    out4 = torch.randn(B, 4 * D, L, device=dev); mm_ = pl(D)
+    rows.append(("cross_merge", t(lambda: lib.mm_cross_merge_fwd(out4.data_ptr(), *P(mm_), B, D, hw, hw, st)), 5 * unit))
+    d2 = pl(2 * D)
+    rows.append(("plane_transpose", t(lambda: lib.mm_plane_transpose(*P(d2), *P(d2[:, D:]), B, D, hw, hw, st)), 2 * unit))
+    du2, du4, xcf, dxc = pl(2 * D), pl(4 * D), pl(D), pl(D)
+    wsc = torch.empty((B, D * lib.mm_dwconv_silu_cross_strips(hw, hw), 10), device=dev)
+    wq, bq = r(D, 1, 3, 3), r(D)
+    rows.append(("dwconv bwd (fused du4)", t(lambda: lib.mm_dwconv_silu_cross_bwd(*P(du2), *P(du4), *P(xcf), wq.data_ptr(), bq.data_ptr(), *P(dxc),
+                                                                                   wsc.data_ptr(), B, D, hw, hw, st)), 8 * unit))
     for name, us, mb in rows:
         print(f"C={C:4d} L={L:5d} {name:<22} {us:8.1f} us  {mb:8.1f} MB  {mb / us * 1e3:8.0f} GB/s")
