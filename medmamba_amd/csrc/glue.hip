@@ -268,6 +268,143 @@ __global__ __launch_bounds__(256) void dwconv_silu_cross_bwd_kernel(const float*
   }
 }
 
+// ---- the same two kernels for planes of <= 256 positions (14x14, 7x7): one WAVEFRONT per plane, 4 planes per workgroup and
+// iteration, each wave with its own LDS tiles (one workgroup of 128 threads per 196- or 49-element plane meant 24,576 /
+// 49,152 workgroups with three barriers and a cross-wave reduction each).  Same arithmetic, same ws layout (nstrips = 1).
+__global__ __launch_bounds__(256) void dwconv_silu_cross_fwd_small_kernel(const float* __restrict__ x, int64_t x_sb, int64_t x_sd,
+                                                                          const float* __restrict__ wgt,
+                                                                          const float* __restrict__ bias, float* __restrict__ u2,
+                                                                          int64_t u_sb, int64_t u_sd, int D, int H, int W,
+                                                                          int nplanes) {
+  extern __shared__ float lds[];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int WP = W + 2, L = H * W;
+  const int per_wave = (H + 2) * WP + H * (W + 1);
+  float* sx = lds + wv * per_wave;         // (H+2) x (W+2), zero border
+  float* so = sx + (H + 2) * WP;           // H x (W+1)
+  const int per_iter = gridDim.x * 4;
+  const int niter = (nplanes + per_iter - 1) / per_iter;
+  for (int it = 0; it < niter; ++it) {
+    const int pl = it * per_iter + blockIdx.x * 4 + wv;
+    const bool okp = pl < nplanes;
+    const int b = okp ? pl / D : 0, d = okp ? pl % D : 0;
+    const float* xp = x + (int64_t)b * x_sb + (int64_t)d * x_sd;
+    for (int i = lane; i < (H + 2) * WP; i += 64) {
+      const int hh = i / WP - 1, ww = i % WP - 1;
+      sx[i] = (okp && hh >= 0 && hh < H && ww >= 0 && ww < W) ? xp[hh * W + ww] : 0.f;
+    }
+    float k[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) k[i] = wgt[d * 9 + i];
+    const float bs = bias ? bias[d] : 0.f;
+    __syncthreads();
+    float* o0 = u2 + b * u_sb + d * u_sd;
+    float* o1 = u2 + b * u_sb + (D + d) * u_sd;
+    for (int i = lane; i < L; i += 64) {
+      const int h = i / W, w = i % W;
+      const float* c = sx + h * WP + w;
+      float p = bs;
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) p = fmaf(c[kh * WP + kw], k[kh * 3 + kw], p);
+      const float v = p * sigmoid_f(p);
+      if (okp) o0[i] = v;
+      so[h * (W + 1) + w] = v;
+    }
+    __syncthreads();
+    for (int i = lane; i < L; i += 64) {      // i = w*H + h
+      const int w = i / H, h = i % H;
+      if (okp) o1[i] = so[h * (W + 1) + w];
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void dwconv_silu_cross_bwd_small_kernel(const float* __restrict__ du2, int64_t g_sb, int64_t g_sd,
+                                                                          const float* __restrict__ du4, int64_t e_sb, int64_t e_sd,
+                                                                          const float* __restrict__ x, int64_t x_sb, int64_t x_sd,
+                                                                          const float* __restrict__ wgt,
+                                                                          const float* __restrict__ bias, float* __restrict__ dx,
+                                                                          int64_t dx_sb, int64_t dx_sd, float* __restrict__ ws,
+                                                                          int D, int H, int W, int nplanes) {
+  extern __shared__ float lds[];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int WP = W + 2, L = H * W;
+  const int per_wave = (H + 2) * WP + (H + 2) * WP + H * (W + 1);
+  float* sx = lds + wv * per_wave;          // (H+2) x (W+2): x with a zero border
+  float* sd = sx + (H + 2) * WP;            // (H+2) x (W+2): dp with a zero border
+  float* st = sd + (H + 2) * WP;            // H x (W+1): the column-major gradient, transposed
+  const int per_iter = gridDim.x * 4;
+  const int niter = (nplanes + per_iter - 1) / per_iter;
+  for (int it = 0; it < niter; ++it) {
+    const int pl = it * per_iter + blockIdx.x * 4 + wv;
+    const bool okp = pl < nplanes;
+    const int b = okp ? pl / D : 0, d = okp ? pl % D : 0;
+    const float* xp = x + (int64_t)b * x_sb + (int64_t)d * x_sd;
+    const float* g0 = du2 + b * g_sb + d * g_sd;
+    const float* g1 = du2 + b * g_sb + (D + d) * g_sd;
+    const float* e0 = du4 ? du4 + b * e_sb + d * e_sd : nullptr;
+    const int64_t eD = (int64_t)D * e_sd;
+    for (int i = lane; i < (H + 2) * WP; i += 64) {
+      const int hh = i / WP - 1, ww = i % WP - 1;
+      sx[i] = (okp && hh >= 0 && hh < H && ww >= 0 && ww < W) ? xp[hh * W + ww] : 0.f;
+      sd[i] = 0.f;
+    }
+    for (int i = lane; i < L; i += 64) {     // i = w*H + h (lanes along h)
+      const int w = i / H, h = i % H;
+      st[h * (W + 1) + w] = okp ? g1[i] + (e0 ? e0[2 * eD + i] + e0[3 * eD + i] : 0.f) : 0.f;
+    }
+    float k[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) k[i] = wgt[d * 9 + i];
+    const float bs = bias ? bias[d] : 0.f;
+    __syncthreads();
+    float acc[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) acc[i] = 0.f;
+    for (int i = lane; i < L; i += 64) {
+      const int h = i / W, w = i % W;
+      const float* c = sx + h * WP + w;
+      float p = bs;
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) p = fmaf(c[kh * WP + kw], k[kh * 3 + kw], p);
+      const float sg = sigmoid_f(p);
+      const float ge = (okp && e0) ? e0[i] + e0[eD + i] : 0.f;
+      const float dp = ((okp ? g0[i] : 0.f) + ge + st[h * (W + 1) + w]) * (sg * (1.f + p * (1.f - sg)));
+      sd[(h + 1) * WP + (w + 1)] = dp;
+      acc[9] += dp;
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) acc[kh * 3 + kw] = fmaf(dp, c[kh * WP + kw], acc[kh * 3 + kw]);
+    }
+    __syncthreads();
+    float* dxp = dx + (int64_t)b * dx_sb + (int64_t)d * dx_sd;
+    for (int i = lane; i < L; i += 64) {
+      const int h = i / W, w = i % W;
+      float v = 0.f;
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) v = fmaf(sd[(h + 2 - kh) * WP + (w - kw + 2)], k[kh * 3 + kw], v);
+      if (okp) dxp[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+      float v = group_sum<16>(acc[i]);
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      if (lane == 0 && okp) ws[(int64_t)pl * 10 + i] = v;
+    }
+    __syncthreads();
+  }
+}
+
+inline int dw_small_grid(int nplanes) { const int b = (nplanes + 15) / 16; return b < 1 ? 1 : b; }   // 4 planes x 4 iterations
+
 // row-strip plan of the two kernels above: whole plane when the backward's three LDS tiles fit 48 KB, else 32-row strips
 // (narrower strips for very wide planes so that a strip always fits)
 struct DwPlan { int SH, nstrips; size_t lds_fwd, lds_bwd; };
@@ -930,6 +1067,12 @@ int mm_dwconv_silu_cross_fwd(const float* x, int64_t x_sb, int64_t x_sd, const f
   if (batch <= 0 || D <= 0 || H <= 0 || W <= 0) return MM_ERR_SHAPE;
   const DwPlan pl = dw_plan(H, W);
   if (pl.lds_bwd > 150 * 1024) return MM_ERR_UNSUPPORTED;
+  if ((int64_t)H * W <= 256) {
+    const size_t lds = sizeof(float) * 4 * ((size_t)(H + 2) * (W + 2) + (size_t)H * (W + 1));
+    hipLaunchKernelGGL(dwconv_silu_cross_fwd_small_kernel, dim3(dw_small_grid(batch * D)), dim3(256), lds, (hipStream_t)stream, x, x_sb, x_sd, w, bias,
+                       u2, u2_sb, u2_sd, D, H, W, batch * D);
+    return (int)hipGetLastError();
+  }
   const int L = pl.SH * W, nt = L >= 1024 ? 256 : (L > 64 ? 128 : 64);
   if (pl.lds_fwd > 64 * 1024) (void)hipFuncSetAttribute((const void*)dwconv_silu_cross_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_fwd);
   hipLaunchKernelGGL(dwconv_silu_cross_fwd_kernel, dim3(batch * D * pl.nstrips), dim3(nt), pl.lds_fwd, (hipStream_t)stream, x, x_sb, x_sd, w, bias, u2,
@@ -945,6 +1088,12 @@ int mm_dwconv_silu_cross_bwd(const float* du2, int64_t du2_sb, int64_t du2_sd, c
   if (batch <= 0 || D <= 0 || H <= 0 || W <= 0) return MM_ERR_SHAPE;
   const DwPlan pl = dw_plan(H, W);
   if (pl.lds_bwd > 150 * 1024) return MM_ERR_UNSUPPORTED;
+  if ((int64_t)H * W <= 256) {
+    const size_t lds = sizeof(float) * 4 * (2 * (size_t)(H + 2) * (W + 2) + (size_t)H * (W + 1));
+    hipLaunchKernelGGL(dwconv_silu_cross_bwd_small_kernel, dim3(dw_small_grid(batch * D)), dim3(256), lds, (hipStream_t)stream, du2, du2_sb, du2_sd,
+                       du4, du4_sb, du4_sd, x, x_sb, x_sd, w, bias, dx, dx_sb, dx_sd, ws, D, H, W, batch * D);
+    return (int)hipGetLastError();
+  }
   const int L = pl.SH * W, nt = L >= 1024 ? 256 : (L > 64 ? 128 : 64);
   if (pl.lds_bwd > 60 * 1024) (void)hipFuncSetAttribute((const void*)dwconv_silu_cross_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_bwd);
   hipLaunchKernelGGL(dwconv_silu_cross_bwd_kernel, dim3(batch * D * pl.nstrips), dim3(nt), pl.lds_bwd, (hipStream_t)stream, du2, du2_sb, du2_sd, du4,
