@@ -39,7 +39,9 @@ def test_synthetic_training_checkpoints_and_resume(tmp_path):
     for k, va in ca["model_state_dict"].items():
         vb = cb["model_state_dict"][k]
         if va.dtype.is_floating_point:
-            assert float((va - vb).abs().max()) <= 2 * lr * resumed_steps + 1e-4 * float(va.abs().max()), k
+            # BatchNorm running statistics follow the activations, which follow every noisy weight before them: relative 1e-3
+            rel = 1e-3 if "running_" in k else 1e-4
+            assert float((va - vb).abs().max()) <= 2 * lr * resumed_steps + rel * float(va.abs().max()), k
         else:
             assert torch.equal(va, vb), k                            # BatchNorm step counters
     w = "layers.0.blocks.0.self_attention.in_proj.weight"
