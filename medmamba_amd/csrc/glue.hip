@@ -7,6 +7,7 @@
 //   The NCHW->NHWC transpose of `left` goes through a 32x33 LDS tile; all global accesses are 128-B runs.
 //   The backward is the same permutation read the other way (d_left, d_ssm from dout; d_inp = dout).
 #include <cstdlib>
+#include <stdlib.h>
 #include "mm_common.h"
 #include "medmamba_hip.h"
 
@@ -123,6 +124,14 @@ int mm_shuffle_residual_bwd(const float* dout, float* dleft, float* dssm, int64_
 // =====================================================================================================
 namespace {
 
+// (quotient, remainder) of a loop index that advances by a fixed step: one division before the loop instead of one per
+// element (an integer division by a runtime value is ~25 VALU instructions; these kernels do ~60 of real work per element)
+struct DivMod {
+  int q, r, dq, dr, d;
+  __device__ __forceinline__ DivMod(int start, int step, int div) : q(start / div), r(start % div), dq(step / div), dr(step % div), d(div) {}
+  __device__ __forceinline__ void next() { q += dq; r += dr; if (r >= d) { r -= d; ++q; } }
+};
+
 // ---- depthwise 3x3 conv + bias + SiLU (MedMamba.py:153-162, 295), writing the scan's two input orders --------
 // x: planes (b, d) of H*W floats, batch stride x_sb, channel stride H*W.  out u2: (batch, 2, D, L):
 // u2[b,0,d,h*W+w] = u2[b,1,d,w*H+h] = silu(conv(x)[b,d,h,w] + bias[d]).
@@ -143,9 +152,12 @@ __global__ __launch_bounds__(256) void dwconv_silu_cross_fwd_kernel(const float*
   float* sx = lds;                         // (sh+2) x (W+2): rows r0-1 .. r0+sh, zero outside the plane
   float* so = lds + (SH + 2) * WP;         // sh x (W+1)
   const float* xp = x + (int64_t)b * x_sb + (int64_t)d * x_sd;
-  for (int i = tid; i < (sh + 2) * WP; i += nt) {
-    const int hh = r0 + i / WP - 1, ww = i % WP - 1;
-    sx[i] = (hh >= 0 && hh < H && ww >= 0 && ww < W) ? xp[hh * W + ww] : 0.f;
+  {
+    DivMod dm(tid, nt, WP);
+    for (int i = tid; i < (sh + 2) * WP; i += nt, dm.next()) {
+      const int hh = r0 + dm.q - 1, ww = dm.r - 1;
+      sx[i] = (hh >= 0 && hh < H && ww >= 0 && ww < W) ? xp[hh * W + ww] : 0.f;
+    }
   }
   float k[9];
 #pragma unroll
@@ -154,8 +166,9 @@ __global__ __launch_bounds__(256) void dwconv_silu_cross_fwd_kernel(const float*
   __syncthreads();
   float* o0 = u2 + b * u_sb + d * u_sd;
   float* o1 = u2 + b * u_sb + (D + d) * u_sd;
-  for (int i = tid; i < sh * W; i += nt) {
-    const int hl = i / W, w = i % W;
+  DivMod dw(tid, nt, W);
+  for (int i = tid; i < sh * W; i += nt, dw.next()) {
+    const int hl = dw.q, w = dw.r;
     const float* c = sx + hl * WP + w;     // top-left of the 3x3 window
     float p = bs;
 #pragma unroll
@@ -167,8 +180,9 @@ __global__ __launch_bounds__(256) void dwconv_silu_cross_fwd_kernel(const float*
     so[hl * (W + 1) + w] = v;
   }
   __syncthreads();
-  for (int i = tid; i < sh * W; i += nt) {      // i = w*sh + hl  (lanes along h: runs of sh floats in the column-major plane)
-    const int w = i / sh, hl = i % sh;
+  DivMod dh(tid, nt, sh);
+  for (int i = tid; i < sh * W; i += nt, dh.next()) {      // i = w*sh + hl  (lanes along h: runs of sh floats in the column-major plane)
+    const int w = dh.q, hl = dh.r;
     o1[w * H + r0 + hl] = so[hl * (W + 1) + w];
   }
 }
@@ -201,13 +215,17 @@ __global__ __launch_bounds__(256) void dwconv_silu_cross_bwd_kernel(const float*
   const float* g1 = du2 + b * g_sb + (D + d) * g_sd;
   const float* e0 = du4 ? du4 + b * e_sb + d * e_sd : nullptr;          // direction 0; direction k at e0 + k*D*e_sd
   const int64_t eD = (int64_t)D * e_sd;
-  for (int i = tid; i < (sh + 4) * WP; i += nt) {
-    const int hh = r0 + i / WP - 2, ww = i % WP - 1;
-    sx[i] = (hh >= 0 && hh < H && ww >= 0 && ww < W) ? xp[hh * W + ww] : 0.f;
+  {
+    DivMod dm(tid, nt, WP);
+    for (int i = tid; i < (sh + 4) * WP; i += nt, dm.next()) {
+      const int hh = r0 + dm.q - 2, ww = dm.r - 1;
+      sx[i] = (hh >= 0 && hh < H && ww >= 0 && ww < W) ? xp[hh * W + ww] : 0.f;
+    }
   }
   for (int i = tid; i < (sh + 2) * WP; i += nt) sd[i] = 0.f;
-  for (int i = tid; i < gh * W; i += nt) {  // i = w*gh + hg (lanes along h)
-    const int w = i / gh, hg = i % gh, h = ge0 + hg;
+  DivMod dg(tid, nt, gh);
+  for (int i = tid; i < gh * W; i += nt, dg.next()) {  // i = w*gh + hg (lanes along h)
+    const int w = dg.q, hg = dg.r, h = ge0 + hg;
     st[(h - (r0 - 1)) * (W + 1) + w] = g1[w * H + h] + (e0 ? e0[2 * eD + w * H + h] + e0[3 * eD + w * H + h] : 0.f);
   }
   float k[9];
@@ -218,8 +236,9 @@ __global__ __launch_bounds__(256) void dwconv_silu_cross_bwd_kernel(const float*
   float acc[10];
 #pragma unroll
   for (int i = 0; i < 10; ++i) acc[i] = 0.f;
-  for (int i = tid; i < gh * W; i += nt) {
-    const int hg = i / W, w = i % W, h = ge0 + hg;
+  DivMod dc(tid, nt, W);
+  for (int i = tid; i < gh * W; i += nt, dc.next()) {
+    const int hg = dc.q, w = dc.r, h = ge0 + hg;
     const int hl = h - (r0 - 1);                        // row inside sd / st (0 .. sh+1)
     const float* c = sx + hl * WP + w;                 // sx row of h-1 is (h-1) - (r0-2) = hl
     float p = bs;
@@ -241,8 +260,9 @@ __global__ __launch_bounds__(256) void dwconv_silu_cross_bwd_kernel(const float*
   }
   __syncthreads();
   float* dxp = dx + (int64_t)b * dx_sb + (int64_t)d * dx_sd;
-  for (int i = tid; i < sh * W; i += nt) {
-    const int hl = i / W, w = i % W;
+  DivMod dxi(tid, nt, W);
+  for (int i = tid; i < sh * W; i += nt, dxi.next()) {
+    const int hl = dxi.q, w = dxi.r;
     // dx[h,w] = sum_{kh,kw} dp[h-kh+1, w-kw+1] * k[kh][kw]   (sd row of h+1-kh is hl + 2 - kh, column offset +1)
     float v = 0.f;
 #pragma unroll
@@ -278,7 +298,7 @@ __global__ __launch_bounds__(256) void dwconv_silu_cross_fwd_small_kernel(const 
                                                                           int nplanes) {
   extern __shared__ float lds[];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int WP = W + 2, L = H * W;
+  const int WP = W + 2;
   const int per_wave = (H + 2) * WP + H * (W + 1);
   float* sx = lds + wv * per_wave;         // (H+2) x (W+2), zero border
   float* so = sx + (H + 2) * WP;           // H x (W+1)
@@ -289,9 +309,12 @@ __global__ __launch_bounds__(256) void dwconv_silu_cross_fwd_small_kernel(const 
     const bool okp = pl < nplanes;
     const int b = okp ? pl / D : 0, d = okp ? pl % D : 0;
     const float* xp = x + (int64_t)b * x_sb + (int64_t)d * x_sd;
-    for (int i = lane; i < (H + 2) * WP; i += 64) {
-      const int hh = i / WP - 1, ww = i % WP - 1;
-      sx[i] = (okp && hh >= 0 && hh < H && ww >= 0 && ww < W) ? xp[hh * W + ww] : 0.f;
+    {
+      DivMod dm(lane, 64, WP);
+      for (int i = lane; i < (H + 2) * WP; i += 64, dm.next()) {
+        const int hh = dm.q - 1, ww = dm.r - 1;
+        sx[i] = (okp && hh >= 0 && hh < H && ww >= 0 && ww < W) ? xp[hh * W + ww] : 0.f;
+      }
     }
     float k[9];
 #pragma unroll
@@ -300,8 +323,8 @@ __global__ __launch_bounds__(256) void dwconv_silu_cross_fwd_small_kernel(const 
     __syncthreads();
     float* o0 = u2 + b * u_sb + d * u_sd;
     float* o1 = u2 + b * u_sb + (D + d) * u_sd;
-    for (int i = lane; i < L; i += 64) {
-      const int h = i / W, w = i % W;
+    for (DivMod dv(lane, 64, W); dv.q < H; dv.next()) {
+      const int i = dv.q * W + dv.r, h = dv.q, w = dv.r;
       const float* c = sx + h * WP + w;
       float p = bs;
 #pragma unroll
@@ -313,8 +336,8 @@ __global__ __launch_bounds__(256) void dwconv_silu_cross_fwd_small_kernel(const 
       so[h * (W + 1) + w] = v;
     }
     __syncthreads();
-    for (int i = lane; i < L; i += 64) {      // i = w*H + h
-      const int w = i / H, h = i % H;
+    for (DivMod dv(lane, 64, H); dv.q < W; dv.next()) {      // i = w*H + h
+      const int i = dv.q * H + dv.r, w = dv.q, h = dv.r;
       if (okp) o1[i] = so[h * (W + 1) + w];
     }
     __syncthreads();
@@ -330,7 +353,7 @@ __global__ __launch_bounds__(256) void dwconv_silu_cross_bwd_small_kernel(const 
                                                                           int D, int H, int W, int nplanes) {
   extern __shared__ float lds[];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int WP = W + 2, L = H * W;
+  const int WP = W + 2;
   const int per_wave = (H + 2) * WP + (H + 2) * WP + H * (W + 1);
   float* sx = lds + wv * per_wave;          // (H+2) x (W+2): x with a zero border
   float* sd = sx + (H + 2) * WP;            // (H+2) x (W+2): dp with a zero border
@@ -346,13 +369,16 @@ __global__ __launch_bounds__(256) void dwconv_silu_cross_bwd_small_kernel(const 
     const float* g1 = du2 + b * g_sb + (D + d) * g_sd;
     const float* e0 = du4 ? du4 + b * e_sb + d * e_sd : nullptr;
     const int64_t eD = (int64_t)D * e_sd;
-    for (int i = lane; i < (H + 2) * WP; i += 64) {
-      const int hh = i / WP - 1, ww = i % WP - 1;
-      sx[i] = (okp && hh >= 0 && hh < H && ww >= 0 && ww < W) ? xp[hh * W + ww] : 0.f;
-      sd[i] = 0.f;
+    {
+      DivMod dm(lane, 64, WP);
+      for (int i = lane; i < (H + 2) * WP; i += 64, dm.next()) {
+        const int hh = dm.q - 1, ww = dm.r - 1;
+        sx[i] = (okp && hh >= 0 && hh < H && ww >= 0 && ww < W) ? xp[hh * W + ww] : 0.f;
+        sd[i] = 0.f;
+      }
     }
-    for (int i = lane; i < L; i += 64) {     // i = w*H + h (lanes along h)
-      const int w = i / H, h = i % H;
+    for (DivMod dv(lane, 64, H); dv.q < W; dv.next()) {     // i = w*H + h (lanes along h)
+      const int i = dv.q * H + dv.r, w = dv.q, h = dv.r;
       st[h * (W + 1) + w] = okp ? g1[i] + (e0 ? e0[2 * eD + i] + e0[3 * eD + i] : 0.f) : 0.f;
     }
     float k[9];
@@ -363,8 +389,8 @@ __global__ __launch_bounds__(256) void dwconv_silu_cross_bwd_small_kernel(const 
     float acc[10];
 #pragma unroll
     for (int i = 0; i < 10; ++i) acc[i] = 0.f;
-    for (int i = lane; i < L; i += 64) {
-      const int h = i / W, w = i % W;
+    for (DivMod dv(lane, 64, W); dv.q < H; dv.next()) {
+      const int i = dv.q * W + dv.r, h = dv.q, w = dv.r;
       const float* c = sx + h * WP + w;
       float p = bs;
 #pragma unroll
@@ -383,8 +409,8 @@ __global__ __launch_bounds__(256) void dwconv_silu_cross_bwd_small_kernel(const 
     }
     __syncthreads();
     float* dxp = dx + (int64_t)b * dx_sb + (int64_t)d * dx_sd;
-    for (int i = lane; i < L; i += 64) {
-      const int h = i / W, w = i % W;
+    for (DivMod dv(lane, 64, W); dv.q < H; dv.next()) {
+      const int i = dv.q * W + dv.r, h = dv.q, w = dv.r;
       float v = 0.f;
 #pragma unroll
       for (int kh = 0; kh < 3; ++kh)
@@ -405,13 +431,15 @@ __global__ __launch_bounds__(256) void dwconv_silu_cross_bwd_small_kernel(const 
 
 inline int dw_small_grid(int nplanes) { const int b = (nplanes + 15) / 16; return b < 1 ? 1 : b; }   // 4 planes x 4 iterations
 
-// row-strip plan of the two kernels above: whole plane when the backward's three LDS tiles fit 48 KB, else 32-row strips
+// row-strip plan of the two kernels above: whole plane when the backward's three LDS tiles fit 32 KB, else 32-row strips
 // (narrower strips for very wide planes so that a strip always fits)
 struct DwPlan { int SH, nstrips; size_t lds_fwd, lds_bwd; };
 inline DwPlan dw_plan(int H, int W) {
   auto need_bwd = [&](int sh) { return sizeof(float) * ((size_t)(sh + 4) * (W + 2) + (size_t)(sh + 2) * (W + 2) + (size_t)(sh + 2) * (W + 1)); };
+  static const size_t whole_kb = [] { const char* e = getenv("MM_DW_WHOLE_KB"); return (size_t)(e ? atoi(e) : 32); }();   // tuning knob; 56x56 planes in two
+  // strips (24 instead of 40 KB of LDS per workgroup: 6 per CU) run the fused backward in 199 instead of 222 us at B = 64
   int SH = H;
-  if (need_bwd(SH) > 48 * 1024) {
+  if (need_bwd(SH) > whole_kb * 1024) {
     SH = 32;
     while (SH > 1 && need_bwd(SH) > 96 * 1024) SH >>= 1;
     if (SH > H) SH = H;

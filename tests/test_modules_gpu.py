@@ -327,7 +327,7 @@ def test_large_planes_run_in_row_strips():
     from medmamba_amd import _lib
     from medmamba_amd.modules import SS2D
     lib = _lib.lib()
-    assert lib.mm_dwconv_silu_cross_strips(56, 56) == 1 and lib.mm_dwconv_silu_cross_strips(120, 120) == 4
+    assert lib.mm_dwconv_silu_cross_strips(28, 28) == 1 and lib.mm_dwconv_silu_cross_strips(56, 56) == 2 and lib.mm_dwconv_silu_cross_strips(120, 120) == 4
     assert lib.mm_dwconv_silu_cross_supported(120, 120) == 1 and lib.mm_dwconv_silu_cross_supported(8, 100000) == 0
     torch.manual_seed(4)
     m = SS2D(d_model=2).to(DEV)
