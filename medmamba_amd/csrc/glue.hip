@@ -977,6 +977,14 @@ inline LnPlan plan_ln(int batch, int D, int L, bool bwd) {
       return pl;
     }
   }
+  if (D <= 128 && bwd && coop && !(two_pass & 2) && (long)batch * L >= 16 * 1024) {
+    // backward for narrow D on many positions (the 56x56 / 96x96 stages): 64 positions per workgroup (256-B runs), one lane per
+    // position in each of 4 waves, D/4 channels per lane — single pass instead of the two-pass kernel (S, B = 64, D = 96: 178 -> 163 us)
+    pl.pw = 64; pl.nw = 4; pl.ppb = 64;
+    const int need4 = (D + 3) / 4;
+    pl.cpl = need4 <= 16 ? 16 : need4 <= 24 ? 24 : 32;
+    return pl;
+  }
   const int tpp = D <= 128 ? 4 : 16;
   const int need = (D + tpp - 1) / tpp;
   // measured (tools/bench_ln_gate.py, B = 64): forward 86 -> 48 / 39 -> 36 / 40 -> 31 / 38 -> 27 us for the four S stages;
@@ -1035,7 +1043,11 @@ int launch_ln_bwdc(const LnPlan& pl, dim3 grid, hipStream_t s, const float* dy, 
                    int64_t dz_sd, float* ws, int D, int L, int npb) {
 #define MM_LN_BWDC(NW_, CPL_) hipLaunchKernelGGL((ln_gate_bwdc_kernel<16, NW_, CPL_>), grid, dim3(NW_ * 64), 2 * D * sizeof(float), s, MM_LN_ARGS_B)
 #define MM_LN_BWDC32(CPL_) hipLaunchKernelGGL((ln_gate_bwdc_kernel<32, 8, CPL_>), grid, dim3(512), 2 * D * sizeof(float), s, MM_LN_ARGS_B)
-  if (pl.pw == 32) {
+  if (pl.pw == 64) {
+#define MM_LN_BWDC64(CPL_) hipLaunchKernelGGL((ln_gate_bwdc_kernel<64, 4, CPL_>), grid, dim3(256), 2 * D * sizeof(float), s, MM_LN_ARGS_B)
+    if (pl.cpl == 16) MM_LN_BWDC64(16); else if (pl.cpl == 24) MM_LN_BWDC64(24); else MM_LN_BWDC64(32);
+#undef MM_LN_BWDC64
+  } else if (pl.pw == 32) {
     if (pl.cpl == 16) MM_LN_BWDC32(16); else MM_LN_BWDC32(24);
   } else if (pl.nw == 4) {
     if (pl.cpl == 16) MM_LN_BWDC(4, 16); else MM_LN_BWDC(4, 24);
