@@ -456,3 +456,30 @@ def test_graphed_blocks_match_eager(monkeypatch):
             assert float((v - w).abs().max()) <= 1e-4 * max(1e-2, float(v.abs().max())), k
         else:
             assert torch.equal(v, w), k
+
+
+@pytest.mark.parametrize("kw", [dict(d_conv=5), dict(conv_bias=False), dict(bias=True), dict(expand=1), dict(dt_rank=5),
+                                dict(expand=3, dt_rank=2, bias=True, conv_bias=False), dict(dropout=0.0, dt_init="constant")],
+                         ids=lambda k: ",".join(f"{a}={b}" for a, b in k.items()))
+def test_ss2d_constructor_variants_fused_vs_module_path(kw):
+    """SS2D's constructor surface (MedMamba.py:124-142) beyond the defaults MedMamba uses: other depthwise kernel sizes (MIOpen
+    conv + fused core), no conv bias, projection biases, other expansion factors and dt ranks.  The fused channel-first path
+    must agree with the module-by-module path (the reference's own op chain around the HIP scan operator), forward and backward."""
+    from medmamba_amd.modules import SS2D
+    torch.manual_seed(11)
+    m = SS2D(d_model=12, **kw).to(DEV)
+    x = torch.randn(2, 6, 10, 12, device=DEV, requires_grad=True)
+    dy = torch.randn(2, 6, 10, 12, device=DEV)
+    y = m(x)
+    y.backward(dy)
+    g = x.grad.clone(); x.grad = None
+    gp = {k: p.grad.clone() for k, p in m.named_parameters()}
+    m.zero_grad()
+    y2 = m.forward_modules(x)
+    y2.backward(dy)
+    _close(y, y2.detach().cpu().numpy(), 5e-5, "y")
+    _close(g, x.grad.cpu().numpy(), 2e-4, "dx")
+    assert set(gp) == {k for k, p in m.named_parameters() if p.grad is not None}
+    for k, p in m.named_parameters():
+        w = p.grad.cpu().numpy()
+        assert np.abs(gp[k].cpu().numpy() - w).max() <= 5e-4 * max(1e-3, np.abs(w).max()), (k, kw)
