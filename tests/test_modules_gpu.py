@@ -483,3 +483,31 @@ def test_ss2d_constructor_variants_fused_vs_module_path(kw):
     for k, p in m.named_parameters():
         w = p.grad.cpu().numpy()
         assert np.abs(gp[k].cpu().numpy() - w).max() <= 5e-4 * max(1e-3, np.abs(w).max()), (k, kw)
+
+
+@pytest.mark.parametrize("kw", [dict(patch_norm=False), dict(attn_drop_rate=0.3), dict(dims=24, depths=[1, 1, 1]),
+                                dict(patch_size=2, in_chans=1), dict(norm_layer=torch.nn.Identity)],
+                         ids=lambda k: ",".join(f"{a}" for a in k))
+def test_vssm_constructor_variants_fused_vs_hooked_path(kw):
+    """VSSM's constructor surface (MedMamba.py:423-470) beyond the defaults: the fused paths against the module-by-module path
+    that a forward hook on any sub-module selects (eval mode: Dropout / DropPath inactive), logits and input gradient."""
+    from medmamba_amd.modules import VSSM
+    torch.manual_seed(5)
+    args = dict(num_classes=4, depths=[1, 1], dims=[16, 32], drop_path_rate=0.0)
+    args.update(kw)
+    if kw.get("norm_layer") is torch.nn.Identity:
+        args["norm_layer"] = lambda d: torch.nn.Identity()
+    net = VSSM(**args).to(DEV).eval()
+    cin, ps = args.get("in_chans", 3), args.get("patch_size", 4)
+    x = torch.randn(2, cin, 8 * ps, 8 * ps, device=DEV, requires_grad=True)
+    y = net(x)
+    y.square().sum().backward()
+    g = x.grad.clone(); x.grad = None
+    handles = [m.register_forward_hook(lambda mod, inp, out: None) for m in net.modules() if not list(m.children())]
+    y2 = net(x)
+    y2.square().sum().backward()
+    for h in handles:
+        h.remove()
+    assert y.shape == (2, 4)
+    _close(y, y2.detach().cpu().numpy(), 1e-4, "logits")
+    _close(g, x.grad.cpu().numpy(), 1e-3, "dx")
