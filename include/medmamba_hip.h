@@ -23,13 +23,14 @@
 #ifndef MEDMAMBA_HIP_H
 #define MEDMAMBA_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-#define MM_ABI_VERSION 17
+#define MM_ABI_VERSION 18
 
 enum mm_status {
   MM_OK = 0,
@@ -57,8 +58,16 @@ enum mm_status {
  * out (fully written); dB, dC (batch, G, N, L) contiguous; dA (dim, N), dD (dim), ddelta_bias (dim):
  * ACCUMULATED into (atomicAdd across batch / channel tiles) — the caller zero-fills dA, dB, dC, dD,
  * ddelta_bias before the call.  dD / ddelta_bias may be NULL when D / delta_bias are NULL.
+ *
+ * The struct is SELF-DESCRIBING (since ABI 18): `struct_size` = sizeof(mm_scan_args) of the header the caller was built against.
+ * The library accepts exactly the sizes at which a release of this header ended the struct — MM_SCAN_ARGS_SIZE_BASE (through
+ * rev_mask), _DBC (through dC_sn), _STRIDED (through o_sd) and the current sizeof — and reads the fields a shorter caller
+ * does not have as zero (= "contiguous", "no fused dt projection").  A LARGER struct (a newer header) is accepted when every
+ * byte beyond this library's sizeof is zero, i.e. the caller uses none of the fields this library does not know.  Anything
+ * else (0, a size in the middle of a field group) returns MM_ERR_SHAPE and nothing is read beyond struct_size bytes.
  */
 typedef struct mm_scan_args {
+  uint32_t struct_size;   /* sizeof(mm_scan_args) as the caller sees it; first member on purpose */
   int32_t batch, dim, L, N, G;
   int32_t delta_softplus;
   const float* u;
@@ -116,6 +125,11 @@ typedef struct mm_scan_args {
   int64_t dts_sb, dts_sg, dts_sn;
   int32_t dt_rank;
 } mm_scan_args;
+
+/* struct sizes earlier layouts of this header ended at (see struct_size above) */
+#define MM_SCAN_ARGS_SIZE_BASE ((uint32_t)offsetof(mm_scan_args, dB_sb))
+#define MM_SCAN_ARGS_SIZE_DBC ((uint32_t)offsetof(mm_scan_args, dout_sb))
+#define MM_SCAN_ARGS_SIZE_STRIDED ((uint32_t)offsetof(mm_scan_args, dt_w))
 
 /* replaces selective_scan_cuda.fwd behind selective_scan_fn (MedMamba.py:273-279) */
 int mm_scan_fwd(const mm_scan_args* args, void* stream);

@@ -11,14 +11,15 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "lib", "libmedmamba_hip.so")
 
-ABI_VERSION = 17        # == MM_ABI_VERSION of include/medmamba_hip.h (checked when the library is loaded)
+ABI_VERSION = 18        # == MM_ABI_VERSION of include/medmamba_hip.h (checked when the library is loaded)
 _f32p = ctypes.c_void_p
 _i64 = ctypes.c_int64
 
 
 class ScanArgs(ctypes.Structure):
-    """Mirror of `struct mm_scan_args` (include/medmamba_hip.h)."""
+    """Mirror of `struct mm_scan_args` (include/medmamba_hip.h); struct_size is filled in on construction."""
     _fields_ = [
+        ("struct_size", ctypes.c_uint32),
         ("batch", ctypes.c_int32), ("dim", ctypes.c_int32), ("L", ctypes.c_int32), ("N", ctypes.c_int32),
         ("G", ctypes.c_int32), ("delta_softplus", ctypes.c_int32),
         ("u", _f32p), ("delta", _f32p), ("A", _f32p), ("B", _f32p), ("C", _f32p), ("D", _f32p),
@@ -37,6 +38,10 @@ class ScanArgs(ctypes.Structure):
         ("dt_w", _f32p), ("dts", _f32p), ("dts_sb", ctypes.c_int64), ("dts_sg", ctypes.c_int64), ("dts_sn", ctypes.c_int64),
         ("dt_rank", ctypes.c_int32),
     ]
+
+    def __init__(self, *args, **kw):
+        super().__init__(*args, **kw)
+        self.struct_size = ctypes.sizeof(ScanArgs)
 
 
 # every symbol include/medmamba_hip.h declares: name -> (restype, argtypes)

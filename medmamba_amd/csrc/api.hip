@@ -1,5 +1,6 @@
 // extern "C" surface of libmedmamba_hip.so — argument validation + dispatch only (include/medmamba_hip.h).
 #include <hip/hip_runtime.h>
+#include <string.h>
 #include "medmamba_hip.h"
 #include "mm_common.h"
 
@@ -10,6 +11,22 @@ int scan_bwd_launch(const mm_scan_args* a, hipStream_t stream);
 
 namespace {
 inline bool al4(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 3) == 0; }
+
+// The caller's struct (struct_size bytes of it) -> a full-size copy whose missing tail reads as zero (medmamba_hip.h).
+int normalize(const mm_scan_args* in, mm_scan_args* out) {
+  if (!in) return MM_ERR_NULL;
+  const uint32_t sz = in->struct_size;
+  if (sz != MM_SCAN_ARGS_SIZE_BASE && sz != MM_SCAN_ARGS_SIZE_DBC && sz != MM_SCAN_ARGS_SIZE_STRIDED && sz < sizeof(mm_scan_args))
+    return MM_ERR_SHAPE;
+  if (sz > 4096) return MM_ERR_SHAPE;
+  const unsigned char* raw = reinterpret_cast<const unsigned char*>(in);
+  for (uint32_t i = sizeof(mm_scan_args); i < sz; ++i)
+    if (raw[i]) return MM_ERR_UNSUPPORTED;     // a newer caller uses a field this library does not know
+  memset(out, 0, sizeof(*out));
+  memcpy(out, in, sz < sizeof(*out) ? sz : sizeof(*out));
+  out->struct_size = (uint32_t)sizeof(*out);
+  return MM_OK;
+}
 
 int check_common(const mm_scan_args* a) {
   if (!a) return MM_ERR_NULL;
@@ -46,15 +63,23 @@ const char* mm_status_string(int s) {
   }
 }
 
-int mm_scan_fwd(const mm_scan_args* a, void* stream) {
-  int rc = check_common(a);
+int mm_scan_fwd(const mm_scan_args* args, void* stream) {
+  mm_scan_args full;
+  int rc = normalize(args, &full);
+  if (rc) return rc;
+  const mm_scan_args* a = &full;
+  rc = check_common(a);
   if (rc) return rc;
   if (!a->out) return MM_ERR_NULL;
   return mm::scan_fwd_launch(a, (hipStream_t)stream);
 }
 
-int mm_scan_bwd(const mm_scan_args* a, void* stream) {
-  int rc = check_common(a);
+int mm_scan_bwd(const mm_scan_args* args, void* stream) {
+  mm_scan_args full;
+  int rc = normalize(args, &full);
+  if (rc) return rc;
+  const mm_scan_args* a = &full;
+  rc = check_common(a);
   if (rc) return rc;
   if (!a->delta || !a->dout || !a->du || !a->ddelta || !a->dA || !a->dB || !a->dC) return MM_ERR_NULL;
   if (a->D && !a->dD) return MM_ERR_NULL;

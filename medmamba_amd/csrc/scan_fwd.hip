@@ -364,14 +364,7 @@ int plan_fwd_variant(int batch, int G, int H, int L) {
   return 1;
 }
 
-int scan_fwd_cl_launch(const mm_scan_args* a, int ns, hipStream_t stream);   // scan_fwd_cl.hip
-
 int scan_fwd_launch(const mm_scan_args* a, hipStream_t stream) {
-  {   // variant low byte 16 + NS: the experimental channel-lane kernel (scan_fwd_cl.hip) with NS states per wavefront;
-      // never chosen by default (measured slower than this file's kernel on every MedMamba shape)
-    const int v = a->variant & 0xff;
-    if (v == 20 || v == 24) return scan_fwd_cl_launch(a, v - 16, stream);
-  }
   FwdParams p;
   p.u = a->u; p.delta = a->delta; p.A = a->A; p.B = a->B; p.C = a->C; p.D = a->D; p.bias = a->delta_bias;
   p.out = a->out; p.x_chk = a->x_chk;

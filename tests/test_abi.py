@@ -47,8 +47,90 @@ def test_struct_layout_matches_header(tmp_path):
     assert got[1:] == [getattr(_lib.ScanArgs, n).offset for n in names]
 
 
+def _integration_snippet():
+    """The ctypes binding INTEGRATION.md §3 shows a maintainer, executed verbatim."""
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = md.split("<!-- abi-snippet:begin")[1].split("<!-- abi-snippet:end -->")[0]
+    code = block.split("```python\n", 1)[1].rsplit("```", 1)[0]
+    ns = {}
+    exec(compile(code, "INTEGRATION.md#abi-snippet", "exec"), ns)
+    return ns
+
+
+def test_integration_md_binding_matches_the_header(tmp_path):
+    """The documented struct is the header's struct (size and every offset), and the documented call reaches the library's
+    argument checks: struct_size accepted, NULL operands reported — not a read past the caller's buffer."""
+    import subprocess
+    ns = _integration_snippet()
+    S = ns["mm_scan_args"]
+    names = [f[0] for f in S._fields_]
+    assert names == [f[0] for f in _lib.ScanArgs._fields_]
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include "medmamba_hip.h"\nint main(void){printf("%zu %u %u %u", sizeof(mm_scan_args), '
+                   'MM_SCAN_ARGS_SIZE_BASE, MM_SCAN_ARGS_SIZE_DBC, MM_SCAN_ARGS_SIZE_STRIDED);'
+                   + "".join(f'printf(" %zu", offsetof(mm_scan_args, {n}));' for n in names) + 'return 0;}\n')
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    assert got[0] == ctypes.sizeof(S)
+    assert got[4:] == [getattr(S, n).offset for n in names]
+    base, dbc, strided = got[1:4]
+    lib = ns["lib"]
+    a = S(struct_size=ctypes.sizeof(S), batch=1, dim=8, L=8, N=16, G=4)
+    assert lib.mm_scan_fwd(ctypes.byref(a), None) == -1             # MM_ERR_NULL: sizes fine, operands missing
+    # struct sizes: every layout the header ever ended at is accepted, anything else is MM_ERR_SHAPE before any other check
+    for sz, want in [(0, -2), (24, -2), (base, -1), (base + 8, -2), (dbc, -1), (strided, -1), (ctypes.sizeof(S) - 4, -2),
+                     (ctypes.sizeof(S), -1)]:
+        a.struct_size = sz
+        assert lib.mm_scan_fwd(ctypes.byref(a), None) == want, sz
+    # a short (older) caller: the library must not look at the bytes behind struct_size — poison them
+    raw = (ctypes.c_ubyte * ctypes.sizeof(S))()
+    ctypes.memmove(raw, ctypes.byref(a), ctypes.sizeof(S))
+    for i in range(strided, ctypes.sizeof(S)):
+        raw[i] = 0xFF                                               # dt_w / dts / dt_rank garbage
+    b = S.from_buffer(raw)
+    b.struct_size = strided
+    assert lib.mm_scan_fwd(ctypes.byref(b), None) == -1            # still "operands missing", not "unsupported dt projection"
+    # a longer (newer) caller: fine while the unknown tail is zero, refused when it is used
+    class Longer(ctypes.Structure):
+        _fields_ = [("base", S), ("future", ctypes.c_int64)]
+    c = Longer()
+    ctypes.memmove(ctypes.byref(c), ctypes.byref(a), ctypes.sizeof(S))
+    c.base.struct_size = ctypes.sizeof(Longer)
+    fn = lib.mm_scan_fwd
+    old = fn.argtypes
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    try:
+        assert fn(ctypes.addressof(c), None) == -1
+        c.future = 1
+        assert fn(ctypes.addressof(c), None) == -3
+    finally:
+        fn.argtypes = old
+
+
+@pytest.mark.gpu
+def test_integration_md_binding_runs_a_forward():
+    """One small forward through exactly the binding INTEGRATION.md shows, checked against the CPU oracle."""
+    import numpy as np
+    from oracle.scan_ref import c_scan_fwd
+    ns = _integration_snippet()
+    g = torch.Generator().manual_seed(3)
+    b, G, H, L, N, R = 2, 4, 12, 68, 16, 2
+    u, delta = torch.randn(b, G * H, L, generator=g), torch.randn(b, G * H, L, generator=g)
+    A = -torch.exp(torch.randn(G * H, N, generator=g) * 0.5)
+    xd = torch.randn(b, G, R + 2 * N, L, generator=g)
+    D, bias = torch.randn(G * H, generator=g), torch.randn(G * H, generator=g) - 3
+    dev = torch.device("cuda:0")
+    xdd = xd.to(dev)
+    out = ns["selective_scan_fwd"](u.to(dev), delta.to(dev), A.to(dev), xdd[:, :, R:R + N], xdd[:, :, R + N:], D.to(dev), bias.to(dev))
+    torch.cuda.synchronize()
+    ref = c_scan_fwd(u, delta, A, xd[:, :, R:R + N], xd[:, :, R + N:], D, bias, True, f64=True)
+    assert np.abs(out.cpu().numpy() - ref).max() <= 1e-4 * np.abs(ref).max()
+
+
 def test_bad_arguments_are_rejected_without_launch():
     a = _lib.ScanArgs()
+    assert a.struct_size == ctypes.sizeof(_lib.ScanArgs)
     assert _lib.lib().mm_scan_fwd(None, None) == -1
     a.batch, a.dim, a.L, a.N, a.G = 1, 6, 8, 16, 4        # dim % G != 0
     assert _lib.lib().mm_scan_fwd(a, None) == -2
