@@ -177,6 +177,9 @@ def main():
     torch.manual_seed(42)                      # identical replicas; random-init weights (no checkpoints offline)
     net = VSSM(num_classes=6, **MEDMAMBA_CONFIGS[args.size]).to(dev)
     net = net.train() if args.mode == "train" else net.eval()
+    if world > 1:
+        from medmamba_amd.trainer import offset_device_rng
+        offset_device_rng(rank, 42)             # identical weights above; DropPath masks drawn per rank from here on
     # gradient exchange: one flat all-reduce after backward (GradSync) unless MM_DDP=torch asks for DistributedDataParallel
     use_torch_ddp = world > 1 and os.environ.get("MM_DDP", "flat") == "torch"
     model = wrap_ddp(net, dev) if use_torch_ddp else net

@@ -10,7 +10,8 @@
 //   backward:  bn_bwd_stats_kernel  g = dy * [y > 0];  partial (sum g, sum g*xhat) per (slice, channel)
 //              bn_apply_bwd_kernel  dx = gamma*rstd*(g - mean(g) - xhat*mean(g*xhat));  dgamma, dbeta
 // Semantics = torch.nn.BatchNorm2d in training mode: biased variance for the normalisation, unbiased for running_var,
-// running = (1 - momentum) * running + momentum * batch.  The ReLU mask in the backward is recomputed from x (y is not read).
+// running = (1 - momentum) * running + momentum * batch.  The ReLU mask in the backward is recomputed from x with the forward's
+// own expression fmaf(x, rstd*gamma, beta - mean*rstd*gamma) (y is not read).
 #include "mm_common.h"
 #include "medmamba_hip.h"
 
@@ -131,10 +132,13 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const float* __restri
   const float mean = mean_in[c], rstd = rstd_in[c], gm = gamma[c], bt = beta[c];
   const int b0 = s * g.nb, b1 = min(b0 + g.nb, g.batch);
   const int hw4 = g.HW >> 2;
+  // ReLU mask: the SAME expression and rounding as the forward's y = fmaf(x, sc, sh) (bn_apply_fwd_kernel), so an element
+  // the forward clamped never passes gradient and vice versa (torch masks on the stored y)
+  const float sc = rstd * gm, sh = bt - mean * sc;
   float s1 = 0.f, s2 = 0.f;
   auto acc = [&](float d, float xv) {
     const float xh = (xv - mean) * rstd;
-    const float gg = (relu && fmaf(xh, gm, bt) <= 0.f) ? 0.f : d;
+    const float gg = (relu && fmaf(xv, sc, sh) <= 0.f) ? 0.f : d;
     s1 += gg; s2 = fmaf(gg, xh, s2);
   };
   for (int b = b0; b < b1; ++b) {
@@ -172,9 +176,10 @@ __global__ __launch_bounds__(256) void bn_apply_bwd_kernel(const float* __restri
   const float m1 = s1 * inv_n, m2 = s2 * inv_n, k = gm * rstd;
   const int b0 = s * g.nb, b1 = min(b0 + g.nb, g.batch);
   const int hw4 = g.HW >> 2;
+  const float sc = rstd * gm, sh = bt - mean * sc;      // the forward's affine: same ReLU mask as bn_apply_fwd_kernel
   auto one = [&](float d, float xv) {
     const float xh = (xv - mean) * rstd;
-    const float gg = (relu && fmaf(xh, gm, bt) <= 0.f) ? 0.f : d;
+    const float gg = (relu && fmaf(xv, sc, sh) <= 0.f) ? 0.f : d;
     return k * (gg - m1 - xh * m2);
   };
   for (int b = b0; b < b1; ++b) {

@@ -439,7 +439,9 @@ inline DwPlan dw_plan(int H, int W) {
   static const size_t whole_kb = [] { const char* e = getenv("MM_DW_WHOLE_KB"); return (size_t)(e ? atoi(e) : 32); }();   // tuning knob; 56x56 planes in two
   // strips (24 instead of 40 KB of LDS per workgroup: 6 per CU) run the fused backward in 199 instead of 222 us at B = 64
   int SH = H;
-  if (need_bwd(SH) > whole_kb * 1024) {
+  // planes of <= 256 positions always run the one-wavefront-per-plane kernels, which write ONE row of partial sums per plane:
+  // the plan (and with it mm_dwconv_silu_cross_strips, which sizes the caller's workspace) must say so whatever the knob is
+  if ((int64_t)H * W > 256 && need_bwd(SH) > whole_kb * 1024) {
     SH = 32;
     while (SH > 1 && need_bwd(SH) > 96 * 1024) SH >>= 1;
     if (SH > H) SH = H;

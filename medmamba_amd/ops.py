@@ -770,4 +770,10 @@ def bn_relu_train(x, bn, relu):
     else:
         momentum = 0.0 if bn.momentum is None else bn.momentum
     rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
-    return BNReluFn.apply(x, bn.weight, bn.bias, rm, rv, bn.eps, momentum, relu)
+    y = BNReluFn.apply(x, bn.weight, bn.bias, rm, rv, bn.eps, momentum, relu)
+    if rm is not None:
+        # the kernel updated the running statistics through raw pointers: bump their version counters like an in-place torch
+        # op would, so that anything keyed on them (SS_Conv_SSM._eval_fold) sees the change even if only the BatchNorm modules
+        # were switched to train() and back (e.g. a BN recalibration pass)
+        torch.autograd.graph.increment_version((rm, rv))
+    return y

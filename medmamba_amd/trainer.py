@@ -44,6 +44,14 @@ def set_seed(seed):
         torch.backends.cudnn.benchmark = False
 
 
+def offset_device_rng(rank, seed):
+    """After the (rank-identical) weight initialisation: give every rank its own device RNG stream, so that DropPath masks and
+    Dropout differ across the replicas of a data-parallel job — the model replicas stay identical, the
+    stochastic-depth draws become independent samples like the data shards."""
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed(seed + 1000003 * (int(rank) + 1))
+
+
 def dataset_defaults(is_npz, epochs=None, batch_size=None, lr=None):
     """(epochs, batch_size, lr, lr_decay_epochs) — train.py:71-85."""
     if is_npz:
@@ -141,24 +149,44 @@ class SyntheticBatches:
 class NpzBatches:
     """`{split}_images.npy` / `{split}_labels.npy` (datasets.py:7-54 of the reference): uint8 images (N,H,W) or (N,H,W,3) ->
     float RGB in [-1, 1] at res x res (Resize + ToTensor + Normalize(0.5, 0.5), train.py:100-110), batched in order or
-    shuffled per epoch.  Arrays are memory-mapped; a batch is converted on the fly."""
+    shuffled per epoch.  Arrays are memory-mapped; a batch is converted on the fly.
 
-    def __init__(self, root_dir, split, batch_size, res, device, shuffle, seed=0):
+    Under torchrun every rank passes its `rank` / `world`: ONE permutation per epoch (seeded by seed + epoch, identical on all
+    ranks) is dealt out round-robin — rank r takes order[r::world] — so an epoch is one pass over the set, split into disjoint
+    shards.  Training shards are padded (by wrapping around) to equal length, because every rank must run the same number of
+    steps for the gradient all-reduce; evaluation shards are NOT padded (every sample is counted exactly once)."""
+
+    def __init__(self, root_dir, split, batch_size, res, device, shuffle, seed=0, rank=0, world=1, pad_to_equal=None):
         self.images = np.load(os.path.join(root_dir, f"{split}_images.npy"), mmap_mode="r")
         self.labels = np.load(os.path.join(root_dir, f"{split}_labels.npy")).reshape(-1).astype(np.int64)
         self.batch_size, self.res, self.device, self.shuffle = batch_size, res, device, shuffle
-        self.rng = np.random.default_rng(seed)
+        self.seed, self.epoch = seed, 0
+        self.rank, self.world = int(rank), max(1, int(world))
+        assert 0 <= self.rank < self.world
+        self.pad_to_equal = shuffle if pad_to_equal is None else pad_to_equal
         self.classes = sorted(int(c) for c in np.unique(self.labels))
 
     @property
     def num_samples(self):
-        return len(self.labels)
+        """Samples this rank iterates over per epoch."""
+        return len(self.shard_indices(self.epoch))
+
+    def shard_indices(self, epoch):
+        n = len(self.labels)
+        order = np.random.default_rng(self.seed + epoch).permutation(n) if self.shuffle else np.arange(n)
+        if self.world == 1:
+            return order
+        if self.pad_to_equal and n % self.world:
+            order = np.concatenate([order, order[:self.world - n % self.world]])
+        return order[self.rank::self.world]
 
     def __len__(self):
-        return (len(self.labels) + self.batch_size - 1) // self.batch_size
+        per = (len(self.labels) + self.world - 1) // self.world if self.pad_to_equal else len(self.shard_indices(0))
+        return (per + self.batch_size - 1) // self.batch_size
 
     def __iter__(self):
-        order = self.rng.permutation(len(self.labels)) if self.shuffle else np.arange(len(self.labels))
+        order = self.shard_indices(self.epoch)
+        self.epoch += 1
         for i in range(0, len(order), self.batch_size):
             idx = np.sort(order[i:i + self.batch_size])
             x = torch.from_numpy(np.ascontiguousarray(self.images[idx])).to(self.device).float().div_(255.0)
@@ -193,15 +221,29 @@ def train_one_epoch(net, batches, optimizer, loss_fn, sync=None, on_step=None):
 
 
 @torch.no_grad()
-def evaluate(net, batches):
-    """Validation accuracy, train.py:293-304 (correct predictions / number of samples)."""
+def evaluate(net, batches, return_counts=False):
+    """Validation accuracy, train.py:293-304 (correct predictions / number of samples).  return_counts: (correct, seen) of this
+    process instead — under torchrun every rank evaluates its own shard and the COUNTS are summed over the ranks (fit())."""
     net.eval()
     correct, seen = None, 0
     for images, labels in batches:
         c = torch.eq(net(images).argmax(dim=1), labels).sum()
         correct = c if correct is None else correct + c
         seen += int(labels.numel())
+    if return_counts:
+        return (float(correct) if correct is not None else 0.0), seen
     return (float(correct) / seen) if seen else 0.0
+
+
+def sharded_accuracy(correct, seen, device="cpu"):
+    """Accuracy over the whole validation set when every rank evaluated its own shard: the (correct, seen) COUNTS are summed
+    over the ranks (an average of per-rank accuracies would weight unequal shards wrongly and, with unsharded readers, count
+    every sample world-size times)."""
+    if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+        t = torch.tensor([correct, seen], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t)
+        correct, seen = float(t[0]), float(t[1])
+    return correct / seen if seen else 0.0
 
 
 def fit(net, train_batches, val_batches, optimizer, scheduler, *, epochs, start_epoch=1, best_acc=0.0, num_classes, class_indices,
@@ -215,11 +257,7 @@ def fit(net, train_batches, val_batches, optimizer, scheduler, *, epochs, start_
         mean_loss = train_one_epoch(net, train_batches, optimizer, loss_fn, sync)
         if scheduler is not None:
             scheduler.step()
-        acc = evaluate(net, val_batches)
-        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
-            t = torch.tensor([acc], device=next(net.parameters()).device, dtype=torch.float64)   # every rank saw its own shard
-            torch.distributed.all_reduce(t)
-            acc = float(t) / torch.distributed.get_world_size()
+        acc = sharded_accuracy(*evaluate(net, val_batches, return_counts=True), device=next(net.parameters()).device)
         log.info("[Epoch %d/%d] Train Loss: %.3f | Val Accuracy: %.3f", epoch, epochs, mean_loss, acc)
         if acc > best_acc:
             best_acc, stale = acc, 0

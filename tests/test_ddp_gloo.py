@@ -94,3 +94,61 @@ def test_wrap_is_identity_without_process_group():
     g = m.weight.grad.clone()
     GradSync(m)()                       # world size 1: nothing to exchange
     assert torch.equal(m.weight.grad, g)
+
+
+def _shard_worker(rank, world, port, root, outdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from medmamba_amd import trainer as T
+    from medmamba_amd.ddp import init_distributed
+    assert init_distributed("gloo") == world
+    tr = T.NpzBatches(root, "train", 4, 8, torch.device("cpu"), shuffle=True, seed=5, rank=rank, world=world)
+    va = T.NpzBatches(root, "val", 4, 8, torch.device("cpu"), shuffle=False, rank=rank, world=world)
+    epochs = [tr.shard_indices(e).tolist() for e in range(2)]
+    steps = [sum(1 for _ in tr) for _ in range(2)]                 # two epochs: the reader advances its own epoch counter
+    # a "model" that predicts the label stored in pixel (0, 0): right on even sample ids, wrong on odd ones (see the fixture)
+    class Net(torch.nn.Module):
+        def forward(self, x):
+            lab = ((x[:, 0, 0, 0] * 0.5 + 0.5) * 255.0).round().long()
+            return torch.nn.functional.one_hot(lab, 4).float()
+    correct, seen = T.evaluate(Net(), va, return_counts=True)
+    acc = T.sharded_accuracy(correct, seen)
+    torch.save(dict(epochs=epochs, steps=steps, len=len(tr), val=va.shard_indices(0).tolist(), correct=correct, seen=seen, acc=acc),
+               os.path.join(outdir, f"s{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_npz_shards_are_disjoint_and_cover_the_set(tmp_path):
+    """ADVICE r2 (train.py under torchrun): one epoch = one pass over the training set split into disjoint per-rank shards of a
+    permutation shared by all ranks (padded to equal step counts); validation shards are disjoint, unpadded, and the accuracy
+    is the ratio of the all-reduced COUNTS."""
+    n_train, n_val = 37, 21
+    rng = np.random.default_rng(0)
+    root = tmp_path / "data"
+    root.mkdir()
+    np.save(root / "train_images.npy", rng.integers(0, 255, (n_train, 8, 8), dtype=np.uint8))
+    np.save(root / "train_labels.npy", rng.integers(0, 4, n_train))
+    vl = rng.integers(0, 4, n_val)
+    vi = rng.integers(0, 255, (n_val, 8, 8), dtype=np.uint8)
+    pred = np.where(np.arange(n_val) % 2 == 0, vl, (vl + 1) % 4)     # what the test "model" will answer: right on even ids
+    vi[:, 0, 0] = pred
+    np.save(root / "val_images.npy", vi)
+    np.save(root / "val_labels.npy", vl)
+    world, port = 2, _free_port()
+    out = tmp_path / "out"
+    out.mkdir()
+    mp.spawn(_shard_worker, args=(world, port, str(root), str(out)), nprocs=world, join=True)
+    r = [torch.load(out / f"s{k}.pt", weights_only=True) for k in range(world)]
+    for e in range(2):
+        a, b = r[0]["epochs"][e], r[1]["epochs"][e]
+        assert len(a) == len(b) == (n_train + 1) // 2                       # padded to equal length
+        assert set(a) | set(b) == set(range(n_train))                        # together: the whole set
+        assert len(set(a) & set(b)) <= 1                                     # disjoint up to the one wrap-around sample
+    assert r[0]["epochs"][0] != r[0]["epochs"][1]                            # a new permutation every epoch
+    assert r[0]["steps"] == r[1]["steps"] == [r[0]["len"]] * 2 == [5, 5]     # same number of optimizer steps on every rank
+    assert sorted(r[0]["val"] + r[1]["val"]) == list(range(n_val))           # validation: disjoint, complete, unpadded
+    assert r[0]["seen"] + r[1]["seen"] == n_val
+    want = float((pred == vl).sum()) / n_val
+    assert r[0]["acc"] == r[1]["acc"] == pytest.approx(want)
+    assert r[0]["correct"] / r[0]["seen"] != pytest.approx(want)             # a single shard's accuracy is NOT the answer

@@ -20,17 +20,24 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, outdir):
+def _worker(rank, world, port, outdir, mode="flat"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
     from medmamba_amd import modules
-    from medmamba_amd.ddp import GradSync, init_distributed
+    from medmamba_amd.ddp import GradSync, init_distributed, wrap_ddp
+    from medmamba_amd.trainer import offset_device_rng
     assert init_distributed("gloo") == world
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
     torch.manual_seed(7 + rank)                 # different initial replicas: the broadcast must make them equal
     net = modules.VSSM(num_classes=3, depths=[1, 1, 1, 1], dims=[16, 32, 64, 128], drop_path_rate=0.0).to(dev).train()
-    sync = GradSync(net)
+    assert modules._TWO_STREAMS                     # the block schedule under test: conv branch on the side stream
+    if mode == "torch":                             # DistributedDataParallel (MM_DDP=torch): bucketed, overlapped with backward
+        model, sync = wrap_ddp(net, dev, bucket_cap_mb=1), None      # small buckets: several all-reduces start mid-backward
+    else:
+        model, sync = net, GradSync(net)
+    offset_device_rng(rank, 7)                      # per-rank device RNG (DropPath masks) after the replicas are identical
+    draw = torch.rand(8, device=dev).cpu()
     opt = torch.optim.AdamW(net.parameters(), lr=1e-3, fused=True)
     g = torch.Generator().manual_seed(100)
     x = torch.randn(8, 3, 64, 64, generator=g)[4 * rank:4 * rank + 4].to(dev)
@@ -38,21 +45,26 @@ def _worker(rank, world, port, outdir):
     losses = []
     for _ in range(3):
         opt.zero_grad(set_to_none=True)
-        loss = torch.nn.functional.cross_entropy(net(x), y)
+        loss = torch.nn.functional.cross_entropy(model(x), y)
         loss.backward()
-        sync()
+        if sync is not None:
+            sync()
         opt.step()
         losses.append(float(loss))
     torch.cuda.synchronize()
-    torch.save(dict(params={k: p.detach().cpu() for k, p in net.named_parameters()}, losses=losses,
+    torch.save(dict(params={k: p.detach().cpu() for k, p in net.named_parameters()}, losses=losses, draw=draw,
                     grads={k: p.grad.detach().cpu() for k, p in net.named_parameters()}), os.path.join(outdir, f"r{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_ranks_on_one_gpu_stay_identical(tmp_path):
+@pytest.mark.parametrize("mode", ["flat", "torch"])
+def test_two_ranks_on_one_gpu_stay_identical(tmp_path, mode):
+    """mode "flat": GradSync (bench.py's default); mode "torch": wrap_ddp = DistributedDataParallel on HIP tensors with the
+    two-stream block schedule (gradients of conv-branch parameters are produced on the side stream while buckets are being
+    reduced).  Same assertions: bitwise identical gradients and parameters on both ranks."""
     world, port = 2, _free_port()
-    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, str(tmp_path), mode), nprocs=world, join=True)
     r0 = torch.load(tmp_path / "r0.pt", weights_only=True)
     r1 = torch.load(tmp_path / "r1.pt", weights_only=True)
     for k in r0["params"]:
@@ -60,3 +72,4 @@ def test_two_ranks_on_one_gpu_stay_identical(tmp_path):
         assert torch.equal(r0["params"][k], r1["params"][k]), k     # same start (broadcast) + same updates
     assert all(abs(a) < 1e3 for a in r0["losses"] + r1["losses"])
     assert r0["losses"] != r1["losses"]                             # different data shards
+    assert not torch.equal(r0["draw"], r1["draw"])                  # per-rank device RNG: DropPath masks differ across ranks

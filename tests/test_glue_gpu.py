@@ -477,3 +477,47 @@ def test_own_batchnorm_relu_vs_torch(shape, relu):
     assert close(own.weight.grad, ref.weight.grad, 2e-5) and close(own.bias.grad, ref.bias.grad, 2e-5)
     assert close(own.running_mean, ref.running_mean, 1e-6) and close(own.running_var, ref.running_var, 2e-6)
     assert int(own.num_batches_tracked) == int(ref.num_batches_tracked) == 2
+
+
+def test_own_batchnorm_relu_mask_is_the_forward_mask():
+    """the backward's ReLU mask must use the forward's own expression y = fmaf(x, rstd*gamma, beta - mean*rstd*gamma)
+    (torch masks on the stored y).  Many pre-activations at or next to zero: wherever the forward output is 0 the input gradient
+    must carry no contribution of dy, and vice versa — compared against nn.BatchNorm2d + ReLU, which masks on y."""
+    from medmamba_amd.ops import bn_relu_train
+    B, C, H, W = 8, 32, 14, 14
+    g = torch.Generator(device=DEV).manual_seed(77)
+    x = torch.randn(B, C, H, W, device=DEV, generator=g)
+    own = torch.nn.BatchNorm2d(C).to(DEV).train()
+    with torch.no_grad():
+        own.weight.copy_(torch.randn(C, device=DEV, generator=g))
+        # beta chosen so that bn(x) of the median element of each channel lands within a few ulps of zero
+        mean, var = x.mean((0, 2, 3)), x.var((0, 2, 3), unbiased=False)
+        med = x.permute(1, 0, 2, 3).reshape(C, -1).median(dim=1).values
+        own.bias.copy_(-(med - mean) / torch.sqrt(var + own.eps) * own.weight)
+    ref = torch.nn.BatchNorm2d(C).to(DEV).train()
+    ref.load_state_dict(own.state_dict())
+    xo, xr = x.clone().requires_grad_(), x.clone().requires_grad_()
+    yo = bn_relu_train(xo, own, True)
+    yr = torch.relu(ref(xr))
+    near = (yr.detach().abs() < 1e-5).float().mean().item()
+    assert near > 0.0                                        # the construction really puts elements at the threshold
+    # a gradient that isolates the mask: dy = 1 on one element per channel-plane would be drowned by the mean terms, so compare
+    # d(sum(y * r)) for random r against the same quantity computed from OUR forward output's mask
+    r = torch.randn(B, C, H, W, device=DEV, generator=g)
+    (yo * r).sum().backward()
+    mask = (yo.detach() > 0).float()
+    # reference gradient of BatchNorm for an upstream gradient r*mask (torch's own BN backward, mask from OUR y)
+    (ref(xr) * (r * mask)).sum().backward()
+    scale = max(1.0, float(xr.grad.abs().max()))
+    assert float((xo.grad - xr.grad).abs().max()) <= 2e-5 * scale
+    assert float((own.weight.grad - ref.weight.grad).abs().max()) <= 2e-5 * max(1.0, float(ref.weight.grad.abs().max()))
+
+
+def test_small_planes_ignore_the_strip_knob():
+    """planes of <= 256 positions always run the one-wavefront-per-plane depthwise-conv kernels (one row of partial
+    sums per plane); mm_dwconv_silu_cross_strips, which sizes the caller's workspace, must say 1 for them."""
+    from medmamba_amd import _lib
+    lib = _lib.lib()
+    for H, W in [(14, 14), (7, 7), (16, 16), (1, 200), (4, 64)]:
+        assert lib.mm_dwconv_silu_cross_strips(H, W) == 1
+    assert lib.mm_dwconv_silu_cross_strips(56, 56) >= 1 and lib.mm_dwconv_silu_cross_strips(96, 96) == 3

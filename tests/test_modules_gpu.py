@@ -426,6 +426,47 @@ def test_graphed_inference_matches_eager():
         assert float((got - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max()))
     with pytest.raises(RuntimeError):
         g(torch.randn(2, 3, 64, 64, device=DEV))
+    # weights change in place (an optimizer step / load_state_dict): the folded constants inside the graph are stale — the
+    # replay notices the version counters and recaptures instead of mixing two sets of weights
+    assert g.captures == 1
+    sd = {k: (v * 1.5 + 0.01 if v.dtype.is_floating_point else v) for k, v in net.state_dict().items()}
+    net.load_state_dict(sd)
+    x = torch.randn(4, 3, 64, 64, device=DEV)
+    got = g(x).clone()
+    assert g.captures == 2
+    with torch.no_grad():
+        want = net(x)
+    assert float((got - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max()))
+    g(x)
+    assert g.captures == 2
+
+
+def test_bn_recalibration_invalidates_the_fold():
+    """only the BatchNorm modules are switched to train() and back (the block's own train() is never called); our BN
+    kernels update the running statistics through raw pointers and must still invalidate the block's folded constants."""
+    from medmamba_amd import modules
+    torch.manual_seed(4)
+    blk = modules.SS_Conv_SSM(hidden_dim=32, drop_path=0.0, norm_layer=torch.nn.LayerNorm).to(DEV).eval()
+    x = torch.randn(2, 12, 12, 32, device=DEV)
+    with torch.no_grad():
+        y0 = blk(x)                                               # builds the fold
+        bns = [m for m in blk.conv33conv33conv11 if isinstance(m, torch.nn.BatchNorm2d)]
+        for bn in bns:
+            bn.train()
+        for _ in range(3):
+            blk(torch.randn_like(x) * 2 + 1)                      # recalibration passes: statistics move
+        for bn in bns:
+            bn.eval()
+        y1 = blk(x)
+    prev = modules._FOLD_BN
+    modules._FOLD_BN = False
+    try:
+        with torch.no_grad():
+            y1_ref = blk(x)
+    finally:
+        modules._FOLD_BN = prev
+    assert float((y1 - y0).abs().max()) > 1e-4
+    assert float((y1 - y1_ref).abs().max()) <= 2e-5 * max(1.0, float(y1_ref.abs().max()))
 
 
 def test_graphed_blocks_match_eager(monkeypatch):

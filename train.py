@@ -80,8 +80,10 @@ def main(argv=None):
                              "{split}_images.npy / {split}_labels.npy (the reference's NPZ layout) or use --synthetic")
         if args.augmentation:
             logging.warning("--augmentation is accepted for flag compatibility; the NPZ reader applies Resize + Normalize only")
-        train_batches = T.NpzBatches(args.train_dir, "train", batch_size, args.res, device, shuffle=True, seed=args.seed + rank)
-        val_batches = T.NpzBatches(args.val_dir, "val", batch_size, args.res, device, shuffle=False)
+        # one pass over the set per epoch, split over the ranks (disjoint shards of one shared permutation per epoch)
+        train_batches = T.NpzBatches(args.train_dir, "train", batch_size, args.res, device, shuffle=True, seed=args.seed, rank=rank,
+                                     world=world)
+        val_batches = T.NpzBatches(args.val_dir, "val", batch_size, args.res, device, shuffle=False, rank=rank, world=world)
         num_classes = args.num_classes if args.num_classes is not None else len(train_batches.classes)
         class_indices = {str(c): str(c) for c in train_batches.classes}
     if rank == 0:
@@ -90,6 +92,8 @@ def main(argv=None):
                  args.medmb_size, num_classes)
 
     net = T.build_model(args.medmb_size, num_classes, args.attn_drop_rate, drop_path_rate=args.drop_path_rate).to(device)
+    if world > 1:
+        T.offset_device_rng(rank, args.seed)      # identical weights above, per-rank DropPath / Dropout draws from here on
     optimizer, scheduler = T.make_optimizer(net, is_npz, lr, decay)
     start_epoch, best_acc = 1, 0.0
     if args.resume:
