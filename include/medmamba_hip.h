@@ -135,6 +135,12 @@ typedef struct mm_scan_args {
 int mm_scan_fwd(const mm_scan_args* args, void* stream);
 /* replaces selective_scan_cuda.bwd behind SelectiveScanFn.backward (autograd of MedMamba.py:273-279) */
 int mm_scan_bwd(const mm_scan_args* args, void* stream);
+/* The launch plan mm_scan_fwd (backward == 0) / mm_scan_bwd (backward != 0) would take for these arguments, without launching
+ * anything (sizes, strides, alignment of the pointers as given — NULL pointers count as aligned — and `variant` are read; no
+ * memory is touched): out[0] = states per lane, out[1] = wavefronts per workgroup, out[2] = workgroups, out[3] = 1 if the
+ * 16-byte vector path is taken, out[4] = 1 for the forward's register-lean kernel, out[5] = 1 if dB / dC leave through
+ * per-workgroup partial planes (deterministic) instead of atomics / plain stores, out[6..7] reserved (0).  For tests and tuning. */
+int mm_scan_plan(const mm_scan_args* args, int backward, int32_t out[8]);
 /* checkpoint interval (steps) of x_chk */
 int mm_scan_chunk(void);
 /* largest dt_rank mm_scan_fwd fuses (mm_scan_args.dt_w) */

@@ -52,6 +52,7 @@ SYMBOLS = {
     "mm_status_string": (ctypes.c_char_p, [ctypes.c_int]),
     "mm_scan_fwd": (ctypes.c_int, [ctypes.POINTER(ScanArgs), ctypes.c_void_p]),
     "mm_scan_bwd": (ctypes.c_int, [ctypes.POINTER(ScanArgs), ctypes.c_void_p]),
+    "mm_scan_plan": (ctypes.c_int, [ctypes.POINTER(ScanArgs), ctypes.c_int, ctypes.POINTER(ctypes.c_int32)]),
     "mm_shuffle_residual_fwd": (ctypes.c_int, [_f32p, _f32p, _i64, _i64, _f32p, _f32p, _f32p] + [ctypes.c_int] * 5 + [ctypes.c_void_p]),
     "mm_dwconv_silu_cross_fwd": (ctypes.c_int, [_f32p, _i64, _i64, _f32p, _f32p, _f32p, _i64, _i64] + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
     "mm_dwconv_silu_cross_supported": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),

@@ -5,8 +5,8 @@
 #include "mm_common.h"
 
 namespace mm {
-int scan_fwd_launch(const mm_scan_args* a, hipStream_t stream);
-int scan_bwd_launch(const mm_scan_args* a, hipStream_t stream);
+int scan_fwd_launch(const mm_scan_args* a, hipStream_t stream, int32_t* plan_out = nullptr);
+int scan_bwd_launch(const mm_scan_args* a, hipStream_t stream, int32_t* plan_out = nullptr);
 }  // namespace mm
 
 namespace {
@@ -86,6 +86,17 @@ int mm_scan_bwd(const mm_scan_args* args, void* stream) {
   if (a->delta_bias && !a->ddelta_bias) return MM_ERR_NULL;
   if (!a->x_chk) return MM_ERR_WORKSPACE;
   return mm::scan_bwd_launch(a, (hipStream_t)stream);
+}
+
+int mm_scan_plan(const mm_scan_args* args, int backward, int32_t* out) {
+  if (!out) return MM_ERR_NULL;
+  mm_scan_args full;
+  int rc = normalize(args, &full);
+  if (rc) return rc;
+  if (full.batch <= 0 || full.dim <= 0 || full.L <= 0 || full.G <= 0 || full.dim % full.G != 0) return MM_ERR_SHAPE;
+  if (full.N != mm::kNState) return MM_ERR_UNSUPPORTED;
+  for (int i = 0; i < 8; ++i) out[i] = 0;
+  return backward ? mm::scan_bwd_launch(&full, nullptr, out) : mm::scan_fwd_launch(&full, nullptr, out);
 }
 
 }  // extern "C"

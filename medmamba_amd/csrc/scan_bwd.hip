@@ -468,7 +468,7 @@ int launch_ns(const BwdParams& p, int nblocks, int waves, bool vec, bool sp, hip
 
 namespace mm {
 
-int scan_bwd_launch(const mm_scan_args* a, hipStream_t stream) {
+int scan_bwd_launch(const mm_scan_args* a, hipStream_t stream, int32_t* plan_out) {
   BwdParams p;
   p.u = a->u; p.delta = a->delta; p.A = a->A; p.B = a->B; p.C = a->C; p.D = a->D; p.bias = a->delta_bias;
   p.x_chk = a->x_chk; p.dout = a->dout; p.du = a->du; p.ddelta = a->ddelta; p.dA = a->dA; p.dB = a->dB;
@@ -532,6 +532,10 @@ int scan_bwd_launch(const mm_scan_args* a, hipStream_t stream) {
                    a->B_sg % 4 == 0 && a->B_sn % 4 == 0 && a->C_sb % 4 == 0 && a->C_sg % 4 == 0 && a->C_sn % 4 == 0 &&
                    p.o_sd % 4 == 0 && p.g_sb % 4 == 0 && p.o_sb % 4 == 0;
   const bool sp = a->delta_softplus != 0;
+  if (plan_out) {     // mm_scan_plan: report, do not launch
+    plan_out[0] = ns; plan_out[1] = waves; plan_out[2] = nblocks; plan_out[3] = vec ? 1 : 0; plan_out[4] = 0;
+    return MM_OK;
+  }
   return ns == 4 ? launch_ns<4>(p, nblocks, waves, vec, sp, stream) : launch_ns<2>(p, nblocks, waves, vec, sp, stream);
 }
 

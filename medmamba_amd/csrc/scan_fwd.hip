@@ -364,7 +364,7 @@ int plan_fwd_variant(int batch, int G, int H, int L) {
   return 1;
 }
 
-int scan_fwd_launch(const mm_scan_args* a, hipStream_t stream) {
+int scan_fwd_launch(const mm_scan_args* a, hipStream_t stream, int32_t* plan_out) {
   FwdParams p;
   p.u = a->u; p.delta = a->delta; p.A = a->A; p.B = a->B; p.C = a->C; p.D = a->D; p.bias = a->delta_bias;
   p.out = a->out; p.x_chk = a->x_chk;
@@ -412,6 +412,10 @@ int scan_fwd_launch(const mm_scan_args* a, hipStream_t stream) {
   bool lean = ns == 4 && p.nwaves_total >= 3 * 1024;
   if (a->variant & (1 << 24)) lean = true;
   if (a->variant & (1 << 25)) lean = false;
+  if (plan_out) {     // mm_scan_plan: report, do not launch
+    plan_out[0] = ns; plan_out[1] = wpb; plan_out[2] = nblocks; plan_out[3] = vec ? 1 : 0; plan_out[4] = lean ? 1 : 0;
+    return MM_OK;
+  }
   switch (ns) {
     case 1: return launch_ns<1>(p, nblocks, wpb, vec, sp, lean, stream);
     case 2: return launch_ns<2>(p, nblocks, wpb, vec, sp, lean, stream);

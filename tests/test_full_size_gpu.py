@@ -1,0 +1,144 @@
+"""GPU: BASELINE configs 3 and 5 at FULL size as a MODEL.
+
+Config 3: MedMamba-S, 64 x 3 x 224 x 224, forward + CE + backward (train.py:277-288 without the optimizer step).
+Config 5: MedMamba-B, 32 x 3 x 384 x 384 (L = 9216 at the first stage).
+
+The CPU oracle cannot run 64 images in seconds, so the checks are those that do not need it at full size:
+  * eval mode makes images independent (BatchNorm uses running statistics): two images of the full batch are compared with the
+    oracle model (oracle.model_ref.vssm_forward + the C scan) run on just those two — this pins the full-batch launch plans
+    (wave counts, channel-major planes, strip counts) to the reference arithmetic;
+  * train mode: the loss and every parameter gradient agree between the two-stream and the single-stream schedule and between
+    batch-major and channel-major plane storage (independent code paths through GEMMs, strides and kernels), finite everywhere;
+  * the scan launch plans taken at these sizes are the ones DESIGN.md describes (mm_scan_plan).
+DropPath is off for parity (it draws from the device RNG).
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _oracle_logits(net, x, pick, depths):
+    from oracle import model_ref as R
+    from oracle.scan_ref import c_selective_scan_fn
+    sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    with torch.no_grad():
+        return R.vssm_forward(sd, x[pick].cpu(), depths, c_selective_scan_fn, training=False).numpy()
+
+
+def _train_pass(net, x, y):
+    net.zero_grad(set_to_none=True)
+    loss = torch.nn.functional.cross_entropy(net(x), y)
+    loss.backward()
+    torch.cuda.synchronize()
+    return float(loss.detach()), {k: p.grad.detach().clone() for k, p in net.named_parameters()}
+
+
+def _compare_grads(g0, g1, what, l2_tol=3e-3, max_tol=2e-2):
+    worst = (0.0, None)
+    for k in g0:
+        a, b = g0[k].double(), g1[k].double()
+        assert torch.isfinite(b).all(), (what, k)
+        den = float(a.norm())
+        if den < 1e-12:
+            continue
+        l2 = float((a - b).norm()) / den
+        mx = float((a - b).abs().max()) / max(1e-6, float(a.abs().max()))
+        worst = max(worst, (l2, k))
+        assert l2 <= l2_tol and mx <= max_tol, (what, k, l2, mx)
+    return worst
+
+
+def _plan(batch, G, H, L, backward, cm=False):
+    """Launch plan the library takes for a contiguous (or channel-major) scan of this shape: dict(ns, waves, blocks, vec, lean)."""
+    from medmamba_amd import _lib
+    a = _lib.ScanArgs()
+    a.batch, a.dim, a.L, a.N, a.G, a.delta_softplus = batch, G * H, L, 16, G, 1
+    if cm:
+        a.u_sb, a.u_sd, a.delta_sb, a.delta_sd = L, batch * L, L, batch * L
+        a.dout_sb, a.dud_sb, a.o_sd = L, L, batch * L
+    else:
+        a.u_sb, a.u_sd, a.delta_sb, a.delta_sd = 2 * H * L, L, G * H * L, L
+    a.B_sb, a.B_sg, a.B_sn = G * 35 * L, 35 * L, L
+    a.C_sb, a.C_sg, a.C_sn = G * 35 * L, 35 * L, L
+    a.u_groups, a.u_map, a.rev_mask = 2, 0x1100, 0b1010
+    out = (ctypes.c_int32 * 8)()
+    rc = _lib.lib().mm_scan_plan(a, int(backward), out)
+    assert rc == 0, rc
+    return dict(ns=out[0], waves=out[1], blocks=out[2], vec=out[3], lean=out[4])
+
+
+def test_config3_S_batch64_full_size(monkeypatch):
+    from medmamba_amd import modules, ops
+    from medmamba_amd.modules import VSSM, MEDMAMBA_CONFIGS
+    cfg = MEDMAMBA_CONFIGS["S"]
+    torch.manual_seed(42)
+    net = VSSM(num_classes=6, drop_path_rate=0.0, **cfg).to(DEV)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(64, 3, 224, 224, generator=g)
+    y = torch.randint(0, 6, (64,), generator=g).to(DEV)
+    xd = x.to(DEV)
+    # (i) eval logits of two images of the full batch vs the oracle model on those two
+    net.eval()
+    with torch.no_grad():
+        got = net(xd).cpu().numpy()
+    pick = [3, 60]
+    want = _oracle_logits(net, x, pick, cfg["depths"])
+    assert np.isfinite(got).all()
+    assert np.abs(got[pick] - want).max() <= 1e-3 * max(1.0, np.abs(want).max()), np.abs(got[pick] - want).max()
+    # (ii) train mode at full size: schedules and layouts agree
+    net.train()
+    monkeypatch.setattr(modules, "_TWO_STREAMS", True)
+    l0, g0 = _train_pass(net, xd, y)
+    assert np.isfinite(l0)
+    monkeypatch.setattr(modules, "_TWO_STREAMS", False)
+    l1, g1 = _train_pass(net, xd, y)
+    assert abs(l1 - l0) <= 2e-6 * abs(l0), (l0, l1)
+    _compare_grads(g0, g1, "two-stream vs single-stream")
+    del g1
+    for layout in ("bm", "cm"):
+        monkeypatch.setattr(ops, "_LAYOUT", layout)
+        l2, g2 = _train_pass(net, xd, y)
+        assert abs(l2 - l0) <= 5e-6 * abs(l0), (layout, l0, l2)
+        _compare_grads(g0, g2, f"auto vs {layout}")
+        del g2
+    # (iii) the launch plans of this configuration
+    p1 = _plan(64, 4, 96, 3136, backward=True)
+    assert p1["vec"] == 1 and p1["ns"] == 2 and p1["waves"] == 12 and p1["blocks"] == 256, p1      # one workgroup per direction
+    p3 = _plan(64, 4, 384, 196, backward=True, cm=True)
+    assert p3["vec"] == 1 and p3["ns"] == 4, p3
+    p4 = _plan(64, 4, 768, 49, backward=True, cm=True)
+    assert p4["ns"] == 4, p4
+    f1 = _plan(64, 4, 96, 3136, backward=False)
+    assert f1["vec"] == 1 and f1["ns"] in (2, 4), f1
+
+
+def test_config5_B_batch32_384_full_size():
+    from medmamba_amd.modules import VSSM, MEDMAMBA_CONFIGS
+    cfg = MEDMAMBA_CONFIGS["B"]
+    torch.manual_seed(42)
+    net = VSSM(num_classes=6, drop_path_rate=0.0, **cfg).to(DEV)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(32, 3, 384, 384, generator=g)
+    y = torch.randint(0, 6, (32,), generator=g).to(DEV)
+    xd = x.to(DEV)
+    net.eval()
+    with torch.no_grad():
+        got = net(xd).cpu().numpy()
+    pick = [0, 17]
+    want = _oracle_logits(net, x, pick, cfg["depths"])
+    assert np.isfinite(got).all()
+    assert np.abs(got[pick] - want).max() <= 1e-3 * max(1.0, np.abs(want).max()), np.abs(got[pick] - want).max()
+    net.train()
+    loss, grads = _train_pass(net, xd, y)
+    assert np.isfinite(loss)
+    for k, v in grads.items():
+        assert torch.isfinite(v).all(), k
+        assert float(v.abs().max()) > 0.0, k
+    # the long-sequence stage (L = 9216, 128 channels per direction): half-width waves (2 states per lane)
+    p1 = _plan(32, 4, 128, 9216, backward=True)
+    assert p1["vec"] == 1 and p1["ns"] == 2, p1
