@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MM_ABI_VERSION 18
+#define MM_ABI_VERSION 19
 
 enum mm_status {
   MM_OK = 0,
@@ -51,8 +51,9 @@ enum mm_status {
  * out: (batch, dim, L) contiguous.
  *
  * x_chk (optional, forward output / backward input): state checkpoints
- * (batch, dim, ceil(L / mm_scan_chunk()), N) contiguous — the state after every chunk of
- * mm_scan_chunk() steps.  Required by mm_scan_bwd; pass NULL to mm_scan_fwd for inference.
+ * batch * ceil(L / mm_scan_chunk()) * dim * N floats, contiguous — the state after every chunk of
+ * mm_scan_chunk() steps, laid out (batch, chunk, dim, N) since ABI 19 (a workspace between the two kernels: callers only
+ * size it).  Required by mm_scan_bwd; pass NULL to mm_scan_fwd for inference.
  *
  * Backward (mm_scan_bwd): dout (batch, dim, L) contiguous in; du, ddelta (batch, dim, L) contiguous
  * out (fully written); dB, dC (batch, G, N, L) contiguous; dA (dim, N), dD (dim), ddelta_bias (dim):
@@ -61,7 +62,7 @@ enum mm_status {
  *
  * The struct is SELF-DESCRIBING (since ABI 18): `struct_size` = sizeof(mm_scan_args) of the header the caller was built against.
  * The library accepts exactly the sizes at which a release of this header ended the struct — MM_SCAN_ARGS_SIZE_BASE (through
- * rev_mask), _DBC (through dC_sn), _STRIDED (through o_sd) and the current sizeof — and reads the fields a shorter caller
+ * rev_mask), _DBC (through dC_sn), _STRIDED (through o_sd), _V18 (through dt_rank) and the current sizeof — and reads the fields a shorter caller
  * does not have as zero (= "contiguous", "no fused dt projection").  A LARGER struct (a newer header) is accepted when every
  * byte beyond this library's sizeof is zero, i.e. the caller uses none of the fields this library does not know.  Anything
  * else (0, a size in the middle of a field group) returns MM_ERR_SHAPE and nothing is read beyond struct_size bytes.
@@ -124,12 +125,25 @@ typedef struct mm_scan_args {
   const float* dts;
   int64_t dts_sb, dts_sg, dts_sn;
   int32_t dt_rank;
+  /* backward, optional (since ABI 19): outputs without atomics — deterministic, nothing to zero-fill.
+   *   dpar_sb != 0: dA, dD, ddelta_bias point at per-batch-item PARTIAL buffers: the gradient contribution of batch item b is
+   *     stored (plain stores, every element written exactly once) at dA + b*dpar_sb (dim*N floats), dD + b*dpar_sb (dim),
+   *     ddelta_bias + b*dpar_sb (dim); the caller sums over b in an order of its choice (mm_ss2d_pack_bwd does it while
+   *     un-packing).  One stride for the three: they are meant to be three offsets into one (batch, S) buffer.
+   *   dBC_sc != 0: when a direction is shared by W > 1 workgroups (mm_scan_plan out[6]), workgroup w of a direction stores its
+   *     partial dB / dC at dB + w*dBC_sc / dC + w*dBC_sc (same strides inside a plane) instead of adding with atomics; the
+   *     caller sums the W planes.  With W == 1 the field is ignored and dB / dC are written in place (plain stores, no
+   *     zero-fill needed either way).  All zero = the ABI-18 behaviour: atomicAdd into zero-filled dA, dD, ddelta_bias (and
+   *     dB / dC when W > 1). */
+  int64_t dpar_sb;
+  int64_t dBC_sc;
 } mm_scan_args;
 
 /* struct sizes earlier layouts of this header ended at (see struct_size above) */
 #define MM_SCAN_ARGS_SIZE_BASE ((uint32_t)offsetof(mm_scan_args, dB_sb))
 #define MM_SCAN_ARGS_SIZE_DBC ((uint32_t)offsetof(mm_scan_args, dout_sb))
 #define MM_SCAN_ARGS_SIZE_STRIDED ((uint32_t)offsetof(mm_scan_args, dt_w))
+#define MM_SCAN_ARGS_SIZE_V18 ((uint32_t)offsetof(mm_scan_args, dpar_sb))
 
 /* replaces selective_scan_cuda.fwd behind selective_scan_fn (MedMamba.py:273-279) */
 int mm_scan_fwd(const mm_scan_args* args, void* stream);
@@ -138,8 +152,10 @@ int mm_scan_bwd(const mm_scan_args* args, void* stream);
 /* The launch plan mm_scan_fwd (backward == 0) / mm_scan_bwd (backward != 0) would take for these arguments, without launching
  * anything (sizes, strides, alignment of the pointers as given — NULL pointers count as aligned — and `variant` are read; no
  * memory is touched): out[0] = states per lane, out[1] = wavefronts per workgroup, out[2] = workgroups, out[3] = 1 if the
- * 16-byte vector path is taken, out[4] = 1 for the forward's register-lean kernel, out[5] = 1 if dB / dC leave through
- * per-workgroup partial planes (deterministic) instead of atomics / plain stores, out[6..7] reserved (0).  For tests and tuning. */
+ * 16-byte vector path is taken, out[4] = 1 for the forward's register-lean kernel; backward only: out[5] = 1 if the call as
+ * given uses no atomics at all (dpar_sb set, and dBC_sc set or one workgroup per direction) = bitwise reproducible,
+ * out[6] = W = workgroups that share a direction (number of dB / dC partial planes the caller must provide for dBC_sc),
+ * out[7] = channel tiles each workgroup walks in turn.  For callers that size partial buffers, tests and tuning. */
 int mm_scan_plan(const mm_scan_args* args, int backward, int32_t out[8]);
 /* checkpoint interval (steps) of x_chk */
 int mm_scan_chunk(void);
@@ -268,11 +284,18 @@ int mm_bn_relu_bwd(const float* dy, const float* x, const float* gamma, const fl
  *   in kernel order g = (row fwd, row rev, col fwd, col rev); every segment starts on a multiple of 64 floats (256 B)
  *   and mm_ss2d_pack_size = total number of floats including that padding.
  * mm_ss2d_pack_bwd: dpacked (gradient in packed layout) -> grads (same segment layout, reference direction order,
- *   A segment = gradient w.r.t. A_logs = dA * A). */
+ *   A segment = gradient w.r.t. A_logs = dA * A).
+ *   nparts > 0: the A / D / bias segments of the gradient are NOT taken from dpacked but summed (fixed order, no atomics) over
+ *   parts[q * S + (i - offset of the A segment)], q < nparts, S = mm_ss2d_pack_parts_size — the per-batch-item partial
+ *   buffers mm_scan_bwd writes with mm_scan_args.dpar_sb = S, dA = parts, dD = parts + (D segment offset - A segment offset),
+ *   ddelta_bias likewise.  nparts = 0 (parts may be NULL): everything from dpacked, as before ABI 19. */
 int mm_ss2d_pack_size(int D, int C, int R, int N);
 int mm_ss2d_pack_fwd(const float* x_proj_w, const float* dt_w, const float* dt_b, const float* A_logs, const float* Ds,
                      float* packed, int D, int C, int R, int N, void* stream);
-int mm_ss2d_pack_bwd(const float* dpacked, const float* packed, float* grads, int D, int C, int R, int N, void* stream);
+int mm_ss2d_pack_bwd(const float* dpacked, const float* packed, const float* parts, float* grads, int D, int C, int R, int N,
+                     int nparts, void* stream);
+/* floats per part of `parts` = size of the [A | D | bias] tail of the packed layout (incl. its padding) */
+int mm_ss2d_pack_parts_size(int D, int C, int R, int N);
 
 /* Bias gradient of the conv branch's convolutions (MedMamba.py:338-346): out[c] = sum over batch and positions of the
  * contiguous NCHW tensor x (batch, C, HW).  When mm_channel_sum_nchw_split(batch, C) > 1 the batch is split over several

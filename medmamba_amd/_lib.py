@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "lib", "libmedmamba_hip.so")
 
-ABI_VERSION = 18        # == MM_ABI_VERSION of include/medmamba_hip.h (checked when the library is loaded)
+ABI_VERSION = 19        # == MM_ABI_VERSION of include/medmamba_hip.h (checked when the library is loaded)
 _f32p = ctypes.c_void_p
 _i64 = ctypes.c_int64
 
@@ -37,6 +37,7 @@ class ScanArgs(ctypes.Structure):
         ("dout_sb", ctypes.c_int64), ("dud_sb", ctypes.c_int64), ("o_sd", ctypes.c_int64),
         ("dt_w", _f32p), ("dts", _f32p), ("dts_sb", ctypes.c_int64), ("dts_sg", ctypes.c_int64), ("dts_sn", ctypes.c_int64),
         ("dt_rank", ctypes.c_int32),
+        ("dpar_sb", ctypes.c_int64), ("dBC_sc", ctypes.c_int64),
     ]
 
     def __init__(self, *args, **kw):
@@ -87,7 +88,8 @@ SYMBOLS = {
     "mm_channel_sum_nchw": (ctypes.c_int, [_f32p, _f32p] + [ctypes.c_int] * 3 + [ctypes.c_void_p]),
     "mm_ss2d_pack_size": (ctypes.c_int, [ctypes.c_int] * 4),
     "mm_ss2d_pack_fwd": (ctypes.c_int, [_f32p] * 6 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
-    "mm_ss2d_pack_bwd": (ctypes.c_int, [_f32p] * 3 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
+    "mm_ss2d_pack_bwd": (ctypes.c_int, [_f32p] * 4 + [ctypes.c_int] * 5 + [ctypes.c_void_p]),
+    "mm_ss2d_pack_parts_size": (ctypes.c_int, [ctypes.c_int] * 4),
 }
 
 _lib = None

@@ -16,7 +16,8 @@ inline bool al4(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 3) == 
 int normalize(const mm_scan_args* in, mm_scan_args* out) {
   if (!in) return MM_ERR_NULL;
   const uint32_t sz = in->struct_size;
-  if (sz != MM_SCAN_ARGS_SIZE_BASE && sz != MM_SCAN_ARGS_SIZE_DBC && sz != MM_SCAN_ARGS_SIZE_STRIDED && sz < sizeof(mm_scan_args))
+  if (sz != MM_SCAN_ARGS_SIZE_BASE && sz != MM_SCAN_ARGS_SIZE_DBC && sz != MM_SCAN_ARGS_SIZE_STRIDED && sz != MM_SCAN_ARGS_SIZE_V18 &&
+      sz < sizeof(mm_scan_args))
     return MM_ERR_SHAPE;
   if (sz > 4096) return MM_ERR_SHAPE;
   const unsigned char* raw = reinterpret_cast<const unsigned char*>(in);

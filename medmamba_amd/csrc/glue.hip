@@ -1457,7 +1457,7 @@ template <bool BWD>
 __global__ __launch_bounds__(256) void ss2d_pack_kernel(const float* __restrict__ s0, const float* __restrict__ s1,
                                                         const float* __restrict__ s2, const float* __restrict__ s3,
                                                         const float* __restrict__ s4, float* __restrict__ dst, int D, int C,
-                                                        int R, int N, PackGrid pg) {
+                                                        int R, int N, PackGrid pg, int nparts) {
   // no runtime-indexed local arrays here: they would live in scratch memory, and a dispatch that needs scratch costs
   // ~12 us of set-up on top of a 2 us kernel (measured)
   const int b = blockIdx.x;
@@ -1481,8 +1481,25 @@ __global__ __launch_bounds__(256) void ss2d_pack_kernel(const float* __restrict_
     const float v = src[j];
     dst[i] = seg == 2 ? -expf(v) : v;
   } else {
-    // s0 = dP (packed), s1 = P (packed): d(A_logs) = dA * A
-    dst[soff + j] = s0[i] * (seg == 2 ? s1[i] : 1.0f);
+    // s0 = dP (packed), s1 = P (packed): d(A_logs) = dA * A.  nparts > 0: the A / D / bias segments of the gradient are
+    // the sum over the per-batch-item partial buffers s2[part][i - off(A)] that mm_scan_bwd filled (mm_scan_args.dpar_sb):
+    // summed here in a fixed order (no atomics anywhere -> reproducible), the same segments of dP are not read
+    float v;
+    if (nparts > 0 && seg >= 2) {
+      const int o5 = (o4 + 4 * D + al) & ~al;
+      const int S = o5 - o2;
+      const float* src = s2 + (i - o2);
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+      int q = 0;
+      for (; q + 4 <= nparts; q += 4) {
+        a0 += src[(int64_t)q * S]; a1 += src[(int64_t)(q + 1) * S]; a2 += src[(int64_t)(q + 2) * S]; a3 += src[(int64_t)(q + 3) * S];
+      }
+      for (; q < nparts; ++q) a0 += src[(int64_t)q * S];
+      v = (a0 + a1) + (a2 + a3);
+    } else {
+      v = s0[i];
+    }
+    dst[soff + j] = v * (seg == 2 ? s1[i] : 1.0f);
   }
 }
 
@@ -1508,16 +1525,22 @@ int mm_ss2d_pack_fwd(const float* x_proj_w, const float* dt_w, const float* dt_b
   if (D <= 0 || C <= 0 || R <= 0 || N <= 0) return MM_ERR_SHAPE;
   const PackGrid pg = pack_grid(D, C, R, N);
   hipLaunchKernelGGL(ss2d_pack_kernel<false>, dim3(pg.blk_off[5]), dim3(256), 0, (hipStream_t)stream, x_proj_w, dt_w, dt_b,
-                     A_logs, Ds, packed, D, C, R, N, pg);
+                     A_logs, Ds, packed, D, C, R, N, pg, 0);
   return (int)hipGetLastError();
 }
 
-int mm_ss2d_pack_bwd(const float* dpacked, const float* packed, float* grads, int D, int C, int R, int N, void* stream) {
-  if (!dpacked || !packed || !grads) return MM_ERR_NULL;
-  if (D <= 0 || C <= 0 || R <= 0 || N <= 0) return MM_ERR_SHAPE;
+int mm_ss2d_pack_parts_size(int D, int C, int R, int N) {
+  const PackSeg L = pack_layout(D, C, R, N);
+  return L.off[5] - L.off[2];
+}
+
+int mm_ss2d_pack_bwd(const float* dpacked, const float* packed, const float* parts, float* grads, int D, int C, int R, int N,
+                     int nparts, void* stream) {
+  if (!dpacked || !packed || !grads || (nparts > 0 && !parts)) return MM_ERR_NULL;
+  if (D <= 0 || C <= 0 || R <= 0 || N <= 0 || nparts < 0) return MM_ERR_SHAPE;
   const PackGrid pg = pack_grid(D, C, R, N);
-  hipLaunchKernelGGL(ss2d_pack_kernel<true>, dim3(pg.blk_off[5]), dim3(256), 0, (hipStream_t)stream, dpacked, packed, nullptr,
-                     nullptr, nullptr, grads, D, C, R, N, pg);
+  hipLaunchKernelGGL(ss2d_pack_kernel<true>, dim3(pg.blk_off[5]), dim3(256), 0, (hipStream_t)stream, dpacked, packed, parts,
+                     nullptr, nullptr, grads, D, C, R, N, pg, nparts);
   return (int)hipGetLastError();
 }
 

@@ -43,7 +43,9 @@ struct BwdParams {
   int64_t u_sb, u_sd, d_sb, d_sd, B_sb, B_sg, B_sn, C_sb, C_sg, C_sn;
   int64_t dB_sb, dB_sg, dB_sn, dC_sb, dC_sg, dC_sn;
   int64_t g_sb, o_sb, o_sd;  // batch stride of dout; batch stride of du / ddelta; channel stride shared by all three
-  int dim, L, G, H, CW, ncw, ntiles, nchk;
+  int64_t dpar_sb;          // != 0: dA / dD / dbias are per-batch-item partial buffers (plain stores, no atomics), batch stride
+  int64_t dBC_sc;           // != 0 (and ncw > 1): dB / dC go to per-channel-tile partial planes, plane stride
+  int dim, L, G, H, CW, ncw, npass, ntiles, nchk;
   int ug;                   // channel blocks in u / dout
   unsigned u_map, rev_mask; // block of group g = (u_map >> 4g) & 15; bit g of rev_mask: group g runs backwards
 };
@@ -74,11 +76,23 @@ __global__ __launch_bounds__(maxthreads_of(NS)) void scan_bwd_kernel(const BwdPa
   constexpr int NLD = CH / RPI;          // row-loads per lane per tensor per tile
   constexpr int TSA = tsa_of(NS);
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int tid = threadIdx.x, lane = tid & 63, nthreads = blockDim.x;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int cw = blockIdx.x % p.ncw;
+  const int nthreads = blockDim.x;
+  const int cwb = blockIdx.x % p.ncw;
   const int bk = blockIdx.x / p.ncw;
   const int grp = bk % p.G, b = bk / p.G;
+  // A workgroup owns channel tiles cwb*npass .. cwb*npass + npass-1 of its (batch, direction) and walks them one after the
+  // other (whole sequence each).  With ncw == 1 it owns ALL channels of the direction: dB / dC leave with plain stores in the
+  // first pass and plain read-modify-writes afterwards (the same thread touches the same address in every pass) — no
+  // atomics, no zero-filled outputs, a fixed summation order.
+  for (int pass = 0; pass < p.npass; ++pass) {
+  // every per-lane quantity of a pass is derived from this opaque zero, so that the compiler recomputes the pass set-up per
+  // pass instead of hoisting it out of the pass loop and keeping it alive through the tile loop (+13 VGPRs = spills at 256)
+  int lane_zero;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(lane_zero));
+  const int tid = threadIdx.x + lane_zero, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cw = cwb * p.npass + pass;
+  if (cw * p.CW >= p.H && pass > 0) break;          // (workgroup-uniform) nothing left in this direction
   const int ugrp = p.ug < p.G ? (int)((p.u_map >> (4 * grp)) & 15) : grp;
   const bool rev = grp < 32 && ((p.rev_mask >> grp) & 1);
 
@@ -104,7 +118,7 @@ __global__ __launch_bounds__(maxthreads_of(NS)) void scan_bwd_kernel(const BwdPa
     gx[j] = 0.f;
   }
   const float Dc = p.D ? p.D[d] : 0.f;
-  const float* chk_base = p.x_chk + ((int64_t)b * p.dim + d) * p.nchk * kNState + g * NS;
+  const float* chk_base = p.x_chk + ((int64_t)b * p.nchk * p.dim + d) * kNState + g * NS;   // (batch, chunk, dim, 16): + ci * dim * 16
   // which of the 2*NS reduced dB/dC sums this lane ends up with (butterfly below).  NS = 4: idx = 4*bit2 + 2*bit3 + bit0 (the
   // lanes with bit1 set hold duplicates and stay out of the store); NS = 2: idx = 2*bit2 + bit1 (duplicates: bit0 set)
   const int ridx = NS == 4 ? ((c >> 2) & 1) * 4 + ((c >> 3) & 1) * 2 + (c & 1) : ((c >> 2) & 1) * 2 + ((c >> 1) & 1);
@@ -125,8 +139,8 @@ __global__ __launch_bounds__(maxthreads_of(NS)) void scan_bwd_kernel(const BwdPa
   const rsrc_t rdd = make_rsrc(p.ddelta + b * p.o_sb + d0 * p.o_sd, ((int64_t)(nrw - 1) * p.o_sd + p.L) * 4);
   const rsrc_t rB = make_rsrc(p.B + b * p.B_sb + grp * p.B_sg, ((int64_t)(kNState - 1) * p.B_sn + p.L) * 4);
   const rsrc_t rC = make_rsrc(p.C + b * p.C_sb + grp * p.C_sg, ((int64_t)(kNState - 1) * p.C_sn + p.L) * 4);
-  float* dBbase = p.dB + b * p.dB_sb + grp * p.dB_sg;
-  float* dCbase = p.dC + b * p.dC_sb + grp * p.dC_sg;
+  float* dBbase = p.dB + b * p.dB_sb + grp * p.dB_sg + cwb * p.dBC_sc;
+  float* dCbase = p.dC + b * p.dC_sb + grp * p.dC_sg + cwb * p.dBC_sc;
   bool rvalid[NLD];
   int uoff[NLD], doff[NLD], ooff[NLD];
   float bv[NLD], dDacc[NLD], dbacc[NLD];
@@ -190,7 +204,10 @@ __global__ __launch_bounds__(maxthreads_of(NS)) void scan_bwd_kernel(const BwdPa
       const int te = t0 + tt;
       if (te < p.L) {
         float* pdst = (which ? dCbase + n * p.dC_sn : dBbase + n * p.dB_sn) + (rev ? p.L - 1 - te : te);
-        if (p.ncw == 1) *pdst = v; else atomicAdd(pdst, v);
+        // owned rows (one workgroup per direction, or this workgroup's partial plane): a plain store in the first pass, then
+        // adds WITHOUT return value — nothing to wait for (a load-add-store here stalls every flush on the load: measured
+        // +10-38 % kernel time), and still a fixed order: one thread, one address, program order
+        if ((p.ncw == 1 || p.dBC_sc != 0) && pass == 0) *pdst = v; else atomicAdd(pdst, v);
       }
     }
   };
@@ -204,10 +221,10 @@ __global__ __launch_bounds__(maxthreads_of(NS)) void scan_bwd_kernel(const BwdPa
   float x0n[NS];
   auto load_chk = [&](int64_t ci, bool ok) {      // NS consecutive states of the checkpoint: one 16-B or 8-B load
     if constexpr (NS == 4) {
-      const float4 v = ok ? *reinterpret_cast<const float4*>(chk_base + ci * kNState) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 v = ok ? *reinterpret_cast<const float4*>(chk_base + ci * ((int64_t)p.dim * kNState)) : make_float4(0.f, 0.f, 0.f, 0.f);
       x0n[0] = v.x; x0n[1] = v.y; x0n[2] = v.z; x0n[3] = v.w;
     } else {
-      const float2 v = ok ? *reinterpret_cast<const float2*>(chk_base + ci * kNState) : make_float2(0.f, 0.f);
+      const float2 v = ok ? *reinterpret_cast<const float2*>(chk_base + ci * ((int64_t)p.dim * kNState)) : make_float2(0.f, 0.f);
       x0n[0] = v.x; x0n[1] = v.y;
     }
   };
@@ -327,14 +344,15 @@ __global__ __launch_bounds__(maxthreads_of(NS)) void scan_bwd_kernel(const BwdPa
             const float Bn = at(Bv[j], e), Cn = at(Cv[j], e);
             const float xc = xs[tt][j];
             const float gxt = fmaf(Cn, gt, gx[j]);
-            const float w = fmaf(-dlu, Bn, xc);        // = a_t * x_{t-1}
-            const float t2 = gxt * w;
+            gx[j] = __builtin_amdgcn_exp2f(dl * A2[j]) * gxt;   // a_t recomputed: keeping 64 more VGPRs would spill
+            // t2 = gxt * a_t * x_{t-1} = gx_new * x_{t-1}: the previous state is in registers, no w = x_t - dlu*B needed — except
+            // for the sub-tile's first step, whose predecessor is the checkpoint (not kept: 4 VGPRs short)
+            const float t2 = tt == 0 ? gxt * fmaf(-dlu, Bn, xc) : gx[j] * xs[tt == 0 ? 0 : tt - 1][j];
             dAacc[j] = fmaf(t2, dl, dAacc[j]);
             s1 = fmaf(t2, An[j], s1);
             s2 = fmaf(gxt, Bn, s2);
             v[NS + j] = gt * xc;
             v[j] = gxt * dlu;
-            gx[j] = __builtin_amdgcn_exp2f(dl * A2[j]) * gxt;   // a_t recomputed: keeping 64 more VGPRs would spill
           }
           // (ddelta', du) partials of this state group -> sum over the 4 rows with two permlane swaps:
           // after swap32+add the lower half holds sum(pa), the upper half sum(pb); swap16 finishes both.
@@ -431,9 +449,13 @@ __global__ __launch_bounds__(maxthreads_of(NS)) void scan_bwd_kernel(const BwdPa
   flush_acc((p.ntiles - 1) & 1, 0);               // accumulators of the last processed tile (tile 0)
 
   // ---- per-channel parameter gradients: reduce in the wave, one atomic per value
+  const bool part = p.dpar_sb != 0;     // per-batch-item partial buffers: every (b, d, n) has exactly one writer
   if (cvalid) {
+    float* dst = p.dA + (part ? b * p.dpar_sb : 0) + (int64_t)d * kNState + g * NS;
 #pragma unroll
-    for (int j = 0; j < NS; ++j) atomicAdd(p.dA + (int64_t)d * kNState + g * NS + j, dAacc[j]);
+    for (int j = 0; j < NS; ++j) {
+      if (part) dst[j] = dAacc[j]; else atomicAdd(dst + j, dAacc[j]);
+    }
   }
 #pragma unroll
   for (int i = 0; i < NLD; ++i) {
@@ -443,10 +465,17 @@ __global__ __launch_bounds__(maxthreads_of(NS)) void scan_bwd_kernel(const BwdPa
     sb += dpp_f<DPP_QUAD_XOR1>(sb); sb += dpp_f<DPP_QUAD_XOR2>(sb); sb += dpp_f<DPP_ROW_HALF_MIRROR>(sb);
     if (q == 0 && rvalid[i]) {
       const int dd = grp * p.H + hc0 + RPI * i;
-      if (p.dD) atomicAdd(p.dD + dd, sD);
-      if (p.dbias) atomicAdd(p.dbias + dd, sb);
+      if (part) {
+        if (p.dD) p.dD[b * p.dpar_sb + dd] = sD;
+        if (p.dbias) p.dbias[b * p.dpar_sb + dd] = sb;
+      } else {
+        if (p.dD) atomicAdd(p.dD + dd, sD);
+        if (p.dbias) atomicAdd(p.dbias + dd, sb);
+      }
     }
   }
+  __syncthreads();      // the next pass reuses the LDS tiles
+  }   // pass
 }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -515,16 +544,40 @@ int scan_bwd_launch(const mm_scan_args* a, hipStream_t stream, int32_t* plan_out
   // fp32 atomics on dB/dC from the workgroups that share a direction (measured: 4-wave workgroups beat 6- and 8-wave ones at
   // stages 2-4: 0.62 vs 0.76 / 0.80 ms, 0.32 vs 0.34 ms)
   const int wmax = ns == 4 ? 8 : 12;
-  int maxw;
-  const int forced = (a->variant >> 16) & 0xff;              // tuning override
-  if (forced > 0) maxw = forced > wmax ? wmax : forced;
-  else if (waves_needed <= wmax && (long)a->batch * a->G >= 256) maxw = wmax;
-  else maxw = ns == 4 ? 4 : 8;   // never fewer: 2-wave workgroups double the atomics and lost everywhere they were measured (B, Bz = 32,
-                                 // 96x96 stage at 4 states per lane: 4.87 ms with 512 x 2 waves, 3.24 ms with 256 x 4, 4.25 ms with 128 x 8)
-  const int ncw0 = (waves_needed + maxw - 1) / maxw;
-  const int waves = (waves_needed + ncw0 - 1) / ncw0;
+  const long pairs = (long)a->batch * a->G;
+  const int forced = (a->variant >> 16) & 0xff;              // tuning override: waves per workgroup
+  const int forced_pass = (a->variant >> 8) & 0xff;          // tuning override: passes per workgroup
+  int waves, ncw, npass = 1;
+  if (forced == 0 && waves_needed <= wmax && pairs >= 256) {
+    waves = waves_needed; ncw = 1;                            // the whole direction in one workgroup, one pass
+  } else {
+    // 4-wave workgroups (8 at 2 states per lane).  Never fewer: 2-wave workgroups lost everywhere they were measured (B, Bz = 32,
+    // 96x96 stage at 4 states per lane: 4.87 ms with 512 x 2 waves, 3.24 ms with 256 x 4, 4.25 ms with 128 x 8); never more
+    // when a direction spans several: at the ONE barrier per tile the whole workgroup waits for its slowest wave, and two
+    // 4-wave workgroups per CU cover each other's waits (measured at stages 2-4: 0.62 vs 0.76 / 0.80 ms for 6 / 8 waves).
+    // Round 3: the grid is sized to what is resident at once (2 workgroups per CU = 512) and every workgroup walks `npass`
+    // channel tiles in turn, instead of 1.5 - 3 rounds of single-tile workgroups: no partially filled last round, B/C of a
+    // direction fetched by `ncw` workgroups instead of waves_needed / 4, and dB / dC shared by 1 - 4 workgroups only.
+    const int wpw = forced > 0 ? (forced > wmax ? wmax : forced) : (ns == 4 ? 4 : 8);
+    const int tiles = (waves_needed + wpw - 1) / wpw;         // channel tiles of wpw waves per direction
+    long want = (512 + pairs - 1) / pairs;                    // workgroups per direction that fill the chip
+    if (want < 1) want = 1;
+    // the largest pass count that divides the tiles evenly (every workgroup of a direction walks the same number) and still
+    // leaves `want` workgroups per direction
+    npass = 1;
+    for (int q = 2; q <= tiles; ++q)
+      if (tiles % q == 0 && tiles / q >= want) npass = q;
+    if (forced_pass > 0) { npass = forced_pass < tiles ? forced_pass : tiles; }
+    ncw = (tiles + npass - 1) / npass;
+    waves = (waves_needed + ncw * npass - 1) / (ncw * npass);
+  }
   p.CW = waves * CH;
-  p.ncw = (p.H + p.CW - 1) / p.CW;
+  p.npass = npass;
+  p.ncw = ncw;
+  // per-batch-item partial buffers for dA / dD / dbias and per-workgroup partial planes for dB / dC (include/medmamba_hip.h):
+  // plain stores only — deterministic, nothing to zero-fill
+  p.dpar_sb = a->dpar_sb;
+  p.dBC_sc = ncw > 1 ? a->dBC_sc : 0;
   const int nblocks = a->batch * a->G * p.ncw;
   const bool vec = (a->L % 4 == 0) && aligned16(a->u) && aligned16(a->delta) && aligned16(a->B) && aligned16(a->C) &&
                    aligned16(a->dout) && aligned16(a->du) && aligned16(a->ddelta) && a->u_sb % 4 == 0 &&
@@ -534,6 +587,8 @@ int scan_bwd_launch(const mm_scan_args* a, hipStream_t stream, int32_t* plan_out
   const bool sp = a->delta_softplus != 0;
   if (plan_out) {     // mm_scan_plan: report, do not launch
     plan_out[0] = ns; plan_out[1] = waves; plan_out[2] = nblocks; plan_out[3] = vec ? 1 : 0; plan_out[4] = 0;
+    plan_out[5] = (ncw == 1 || a->dBC_sc != 0) && a->dpar_sb != 0;      // no atomics anywhere: bitwise reproducible
+    plan_out[6] = ncw; plan_out[7] = npass;
     return MM_OK;
   }
   return ns == 4 ? launch_ns<4>(p, nblocks, waves, vec, sp, stream) : launch_ns<2>(p, nblocks, waves, vec, sp, stream);

@@ -29,6 +29,13 @@ namespace {
 using namespace mm;
 
 constexpr int fwd_tile(int ns, bool lean) { return (lean && ns >= 2) ? 32 : 64; }
+// B / C tiles lie in LDS as [time step][16 states] rows of kBCS floats (16 + 4 pad: 16-B aligned rows, and the staging writes of
+// a wave spread over the banks): the NS states of a lane at one time step are ONE ds_read_b32/b64/b128, and they arrive as
+// adjacent registers — operand pairs of v_pk_fma_f32 / v_pk_mul_f32 (two states per instruction)
+// (18 for 2 states per lane: 8-B aligned rows suffice for ds_read_b64, and 2 x 64 x 20 floats would push a 2-wave workgroup
+// over 160 KB / 6 — the 56x56 stage runs 3072 such waves and needs all 3 per SIMD resident at once)
+constexpr int bcs_of(int ns) { return ns == 4 ? 20 : 18; }
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 struct FwdParams {
   const float* __restrict__ u;
@@ -78,7 +85,8 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(const FwdParams p) {
   constexpr int NLD = CH / RPI;                   // float4 row-loads per lane per tensor per tile
   constexpr int NBC = 2 * kNState / RPI;          // float4 B/C staging loads per lane per tile
   constexpr int NPBC = LEAN ? 1 : NBC;
-  constexpr int WLDS = 2 * CH * kTileStride + 2 * kNState * kTileStride;   // floats of LDS per wave
+  constexpr int kBCS = bcs_of(NS);
+  constexpr int WLDS = 2 * CH * kTileStride + 2 * kTile * kBCS;            // floats of LDS per wave
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
   const int lane = threadIdx.x & 63;
@@ -100,7 +108,7 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(const FwdParams p) {
   float* wl = smem + wave * WLDS;
   float* s_dl = wl;                                   // [CH][kTileStride]   delta'
   float* s_du = wl + CH * kTileStride;                // [CH][kTileStride]   delta'*u, then y (in place)
-  float* s_bc = wl + 2 * CH * kTileStride;            // [2][16][kTileStride] B, C
+  float* s_bc = wl + 2 * CH * kTileStride;            // [2][kTile][kBCS] B, C: row = position inside the tile, column = state
 
   // ---- recurrence identity: lane -> (channel c, state group g)
   const int c = lane / SG, g = lane % SG;
@@ -225,7 +233,8 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(const FwdParams p) {
       const int n = (k % (NBC / 2)) * RPI + r;
       const bool isC = k >= NBC / 2;
       const float4 v = LEAN ? load_quad<VEC, VEC>(isC ? rC : rB, bcoff[k], t0 + 4 * q, p.L, rev, true) : pbc[LEAN ? 0 : k];
-      *reinterpret_cast<float4*>(s_bc + ((isC ? kNState : 0) + n) * kTileStride + 4 * qc) = v;
+      float* dst = s_bc + ((isC ? kTile : 0) + 4 * qc) * kBCS + n;      // 4 positions of state n (transposed into [t][n])
+      dst[0] = v.x; dst[kBCS] = v.y; dst[2 * kBCS] = v.z; dst[3 * kBCS] = v.w;
     }
     // the previous tile's stores go out here: older than the loads issued next, so the wait for those
     // loads (one recurrence later) retires them for free and every path sees the same vmcnt picture
@@ -237,20 +246,26 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(const FwdParams p) {
     // ---- phase 2: the recurrence over this tile, 4 steps per group
     const int tlen = min(kTile, p.L - t0);
     const int ngroups = (p.dbg & 2) ? 0 : (tlen + 3) >> 2;
-    const float* sB = s_bc + (g * NS) * kTileStride;
-    const float* sC = s_bc + (kNState + g * NS) * kTileStride;
-    struct Ops { float4 dl4, du4, Bv[NS], Cv[NS]; };
+    const float* sB = s_bc + g * NS;                               // this lane's states inside a [t][16] row
+    const float* sC = s_bc + kTile * kBCS + g * NS;
+    struct Ops { float4 dl4, du4; float Bt[4][NS], Ct[4][NS]; };
     auto phase2 = [&](auto rvtag) {
-    constexpr bool RV = decltype(rvtag)::value;          // mirrored tile: time group tg in column QL-1-tg, step e in component 3-e
+    constexpr bool RV = decltype(rvtag)::value;          // mirrored tile: time step tau lies at position kTile-1-tau
+    auto load_row = [](const float* src, float (&dst)[NS]) {
+      if constexpr (NS == 4) { const float4 v = *reinterpret_cast<const float4*>(src); dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w; }
+      else if constexpr (NS == 2) { const float2 v = *reinterpret_cast<const float2*>(src); dst[0] = v.x; dst[1] = v.y; }
+      else dst[0] = src[0];
+    };
     auto load_ops = [&](int tg) {
       Ops o;
       const int col = RV ? QL - 1 - tg : tg;
       o.dl4 = *reinterpret_cast<const float4*>(s_dl + c * kTileStride + 4 * col);
       o.du4 = *reinterpret_cast<const float4*>(s_du + c * kTileStride + 4 * col);
 #pragma unroll
-      for (int j = 0; j < NS; ++j) {
-        o.Bv[j] = *reinterpret_cast<const float4*>(sB + j * kTileStride + 4 * col);
-        o.Cv[j] = *reinterpret_cast<const float4*>(sC + j * kTileStride + 4 * col);
+      for (int e = 0; e < 4; ++e) {
+        const int row = RV ? kTile - 1 - (4 * tg + e) : 4 * tg + e;
+        load_row(sB + row * kBCS, o.Bt[e]);
+        load_row(sC + row * kBCS, o.Ct[e]);
       }
       return o;
     };
@@ -258,29 +273,60 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(const FwdParams p) {
       auto at = [](const float4& v, int e) { return f4get(v, RV ? 3 - e : e); };
       // all 4*NS decay factors of the group first, then the dependent FMA chains: a v_exp_f32 result that is consumed
       // 2-3 instructions later stalls a wave that has no partner on its SIMD (the transcendental pipe takes 8 cycles
-      // per instruction, but it runs beside the VALU) — keeping the two blocks apart removes that exposure
-      float a[4][NS];
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int j = 0; j < NS; ++j) a[e][j] = __builtin_amdgcn_exp2f(at(o.dl4, e) * A2[j]);
-      __builtin_amdgcn_sched_barrier(0);
+      // per instruction, but it runs beside the VALU) — keeping the two blocks apart removes that exposure.
+      // The multiplies and FMAs work on PAIRS of states (v2f -> v_pk_mul_f32 / v_pk_fma_f32, the per-step scalars delta',
+      // delta'*u broadcast by op_sel): 2.5 instead of 4 VALU per state-step next to the v_exp_f32.
       float4 y4;
+      if constexpr (NS >= 2) {
+        constexpr int NP = NS / 2;
+        v2f a[4][NP];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float du = at(o.du4, e);
-        float y = 0.f;
+        for (int e = 0; e < 4; ++e)
 #pragma unroll
-        for (int j = 0; j < NS; ++j) {
-          x[j] = fmaf(a[e][j], x[j], du * at(o.Bv[j], e));
-          y = fmaf(x[j], at(o.Cv[j], e), y);
+          for (int jj = 0; jj < NP; ++jj) {
+            const v2f pw = (v2f){A2[2 * jj], A2[2 * jj + 1]} * at(o.dl4, e);
+            a[e][jj] = (v2f){__builtin_amdgcn_exp2f(pw.x), __builtin_amdgcn_exp2f(pw.y)};
+          }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float du = at(o.du4, e);
+          v2f yy = {0.f, 0.f};
+#pragma unroll
+          for (int jj = 0; jj < NP; ++jj) {
+            v2f xx = {x[2 * jj], x[2 * jj + 1]};
+            xx = a[e][jj] * xx + (v2f){o.Bt[e][2 * jj], o.Bt[e][2 * jj + 1]} * du;
+            yy = xx * (v2f){o.Ct[e][2 * jj], o.Ct[e][2 * jj + 1]} + yy;
+            x[2 * jj] = xx.x; x[2 * jj + 1] = xx.y;
+          }
+          (&y4.x)[RV ? 3 - e : e] = group_sum<SG>(yy.x + yy.y);
         }
-        (&y4.x)[RV ? 3 - e : e] = group_sum<SG>(y);
+      } else {
+        float a[4][NS];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int j = 0; j < NS; ++j) a[e][j] = __builtin_amdgcn_exp2f(at(o.dl4, e) * A2[j]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float du = at(o.du4, e);
+          float y = 0.f;
+#pragma unroll
+          for (int j = 0; j < NS; ++j) {
+            x[j] = fmaf(a[e][j], x[j], du * o.Bt[e][j]);
+            y = fmaf(x[j], o.Ct[e][j], y);
+          }
+          (&y4.x)[RV ? 3 - e : e] = group_sum<SG>(y);
+        }
       }
       if (g == 0) *reinterpret_cast<float4*>(s_du + c * kTileStride + 4 * (RV ? QL - 1 - tg : tg)) = y4;
       if (p.x_chk != nullptr && ((tg & 3) == 3 || tg == ngroups - 1) && cvalid) {
         const int chunk = (t0 >> 4) + (tg >> 2);   // kChunk = 16 divides both tile sizes
-        float* dst = p.x_chk + (((int64_t)b * p.dim + d) * p.nchk + chunk) * kNState + g * NS;
+        // layout (batch, chunk, dim, 16): the 16 states of a wave's 4*NS channels are ONE contiguous run (1 KB at NS = 4), for
+        // this store and for the backward kernel's load alike ((batch, dim, chunk, 16) scattered 64-B pieces: the training
+        // forward ran 45 % slower than the inference forward at the 14x14 stage)
+        float* dst = p.x_chk + (((int64_t)b * p.nchk + chunk) * p.dim + d) * kNState + g * NS;
 #pragma unroll
         for (int j = 0; j < NS; ++j) dst[j] = x[j];
       }
@@ -326,7 +372,7 @@ template <int NS, bool VEC, bool SP, bool LEAN, bool DT = false>
 int launch(const FwdParams& p, int nblocks, int wpb, hipStream_t stream) {
   constexpr int CH = 4 * NS;
   constexpr int TS = fwd_tile(NS, LEAN) + 4;
-  const size_t lds = sizeof(float) * (size_t)wpb * (2 * CH * TS + 2 * kNState * TS);
+  const size_t lds = sizeof(float) * (size_t)wpb * (2 * CH * TS + 2 * fwd_tile(NS, LEAN) * bcs_of(NS));
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute((const void*)scan_fwd_kernel<NS, VEC, SP, LEAN, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   FwdParams q = p;
@@ -358,7 +404,7 @@ namespace mm {
 int plan_fwd_variant(int batch, int G, int H, int L) {
   (void)L;
   const long seqs = (long)batch * G * H;
-  if (seqs / 16 >= 2048) return 4;     // >= 2 waves per SIMD at 4 states per lane (B, Bz = 32, 48x48 stage: 2048 waves of 4
+  if (seqs / 16 >= 1280) return 4;     // (round 3, packed math: 4 states per lane win from 1536 waves on — S, Bz = 64, 56x56: 0.39 vs 0.50 ms)     // >= 2 waves per SIMD at 4 states per lane (B, Bz = 32, 48x48 stage: 2048 waves of 4
                                        // states 0.33 ms vs 4096 waves of 2 states 0.44 ms); LEAN from 3 per SIMD, see below
   if (seqs / 8 >= 1024) return 2;      // fewer sequences: halve the states per lane to double the wave count
   return 1;

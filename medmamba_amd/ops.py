@@ -382,20 +382,25 @@ class SS2DCoreFn(torch.autograd.Function):
             rc = lib.mm_plane_transpose(*_pl(dout2), *_pl(d1), Bsz, D, H, W, _stream())
             _lib.check(rc, "mm_plane_transpose")
         wsum = ws.sum(0)
-        # gradient of the packed parameters: the A / D / bias segments are accumulated with atomics -> one zero-fill
+        # gradient of the packed parameters: the GEMMs below write the two weight segments of dP; the A / D / bias segments come
+        # from per-batch-item partial buffers that the scan kernel fills with plain stores and mm_ss2d_pack_bwd sums in a
+        # fixed order (no atomics, no zero-fill: bitwise reproducible)
         dP = torch.empty_like(P)
         dWx, dWdt, dA, dD, ddb = SS2DCoreFn._segments(dP, D, C, R, N)
-        dP[dA.storage_offset() - dP.storage_offset():].zero_()
-        # d(x_dbl): dB / dC rows are accumulated by the kernel (atomics when a direction spans several workgroups)
+        S = lib.mm_ss2d_pack_parts_size(D, C, R, N)
+        oA = dA.storage_offset()
+        parts = torch.empty((Bsz, S), device=dev, dtype=torch.float32)
+        # d(x_dbl): the dB / dC rows are fully written by the kernel (in place, or summed from per-workgroup planes), the dt rows
+        # by the GEMM below
         if cm:
-            dx_dbl = torch.zeros((4, C, Q), device=dev, dtype=torch.float32)
+            dx_dbl = torch.empty((4, C, Q), device=dev, dtype=torch.float32)
             xb, dxb = x_dbl.view(4, C, Bsz, L).permute(2, 0, 1, 3), dx_dbl.view(4, C, Bsz, L).permute(2, 0, 1, 3)
         else:
-            dx_dbl = torch.zeros((Bsz, 4, C, L), device=dev, dtype=torch.float32)
+            dx_dbl = torch.empty((Bsz, 4, C, L), device=dev, dtype=torch.float32)
             xb, dxb = x_dbl, dx_dbl
         du4, ddelta = _launch_bwd(u2, delta, A, xb[:, :, R:R + N], xb[:, :, R + N:], Dp, dbias, x_chk, dout2, True,
-                                  _CROSS_SHARED, dBC=(dxb[:, :, R:R + N], dxb[:, :, R + N:]), dparams=(dA, dD, ddb),
-                                  channel_major=cm)[:2]
+                                  _CROSS_SHARED, dBC_dst=dxb[:, :, R:],
+                                  parts=(parts, 0, dD.storage_offset() - oA, ddb.storage_offset() - oA), channel_major=cm)[:2]
         if cm:
             dd = ddelta.permute(1, 0, 2).reshape(4, D, Q)                                      # views of (4D, B, L) storage
             torch.bmm(dd, x_dbl[:, :R].transpose(1, 2), out=dWdt)                               # (4, D, R)
@@ -427,7 +432,7 @@ class SS2DCoreFn(torch.autograd.Function):
             du2 = du2.view(Bsz, 2 * D, L)
         G = torch.empty_like(P)
         with _lib.device_guard(dev):
-            rc = lib.mm_ss2d_pack_bwd(dP.data_ptr(), P.data_ptr(), G.data_ptr(), D, C, R, N, _stream())
+            rc = lib.mm_ss2d_pack_bwd(dP.data_ptr(), P.data_ptr(), parts.data_ptr(), G.data_ptr(), D, C, R, N, Bsz, _stream())
         _lib.check(rc, "mm_ss2d_pack_bwd")
         gWx, gWdt, gA, gD, gb = SS2DCoreFn._segments(G, D, C, R, N)
         dcw = dcb = None

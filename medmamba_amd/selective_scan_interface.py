@@ -7,6 +7,8 @@ Only the variant that exists on the MedMamba path is implemented natively (SURVE
 real A, B/C of shape (batch, G, N, L), z=None, return_last_state=False, N = 16, fp32.
 Anything else raises NotImplementedError; CPU tensors raise RuntimeError (no CPU fallback).
 """
+import ctypes
+
 import torch
 
 from . import _lib
@@ -132,7 +134,7 @@ def _launch_fwd(u, delta, A, B, C, D, delta_bias, delta_softplus, want_chk, vari
     x_chk = None
     if want_chk:
         chunk = _lib.scan_chunk()
-        x_chk = torch.empty((batch, dim, (L + chunk - 1) // chunk, A.shape[1]), device=u.device, dtype=torch.float32)
+        x_chk = torch.empty((batch, (L + chunk - 1) // chunk, dim, A.shape[1]), device=u.device, dtype=torch.float32)
     a = _lib.ScanArgs()
     _fill_common(a, u, delta, A, B, C, D, delta_bias, delta_softplus)
     a.out, a.x_chk, a.variant = out.data_ptr(), _ptr(x_chk), int(variant) or _FWD_VARIANT
@@ -150,13 +152,31 @@ def _launch_fwd(u, delta, A, B, C, D, delta_bias, delta_softplus, want_chk, vari
     return out, x_chk
 
 
-def _launch_bwd(u, delta, A, B, C, D, delta_bias, x_chk, dout, delta_softplus, shared=(0, 0, 0), dBC=None, dparams=None,
+def _like_strided(dst, lead):
+    """Uninitialised fp32 (lead, *dst.shape) whose planes have the same dimension order in memory as the view `dst` (dense)."""
+    order = sorted(range(dst.dim()), key=lambda d: (-dst.stride(d), d))
+    shape = [dst.shape[d] for d in order]
+    t = torch.empty([lead] + shape, device=dst.device, dtype=torch.float32)
+    inv = [0] * dst.dim()
+    for pos, d in enumerate(order):
+        inv[d] = pos + 1
+    return t.permute([0] + inv)
+
+
+def _launch_bwd(u, delta, A, B, C, D, delta_bias, x_chk, dout, delta_softplus, shared=(0, 0, 0), dBC_dst=None, parts=None,
                 channel_major=False):
     """mm_scan_bwd on torch's current stream. Returns du (per group), ddelta, dA, dB, dC, dD, dbias.
-    dBC: optional (dB_view, dC_view) — zero-filled (batch, G, N, L) views (unit stride along L) to accumulate into,
-    e.g. row blocks of the gradient of x_dbl.  dparams: optional zero-filled (dA (dim, N), dD (dim), dbias (dim)).
+
+    No atomics and nothing to zero-fill (ABI 19): dA / dD / dbias are written per batch item into a partial buffer
+    (mm_scan_args.dpar_sb) and dB / dC either in place (one workgroup per direction) or into per-workgroup partial planes
+    (mm_scan_args.dBC_sc) that are summed here — every sum runs in a fixed order, so two runs give the same bits.
+
+    dBC_dst: optional (batch, G, 2N, L) fp32 view with unit stride along L — rows [0, N) receive dB, rows [N, 2N) dC (e.g.
+      the B | C row block of the gradient of x_dbl); fully overwritten.  None: allocated here.
+    parts: optional (buffer (batch, S), offset of dA, offset of dD, offset of dbias) — the caller sums over the batch itself
+      (mm_ss2d_pack_bwd); dA / dD / dbias are then returned as None.  None: allocated and summed here.
     channel_major: du / ddelta are returned as (batch, dim, L) views of (dim, batch, L) storage; dout must then have the
-    same channel stride (batch * L)."""
+      same channel stride (batch * L)."""
     batch, dim, L = delta.shape
     G, N = B.shape[1], A.shape[1]
     dev = u.device
@@ -167,37 +187,56 @@ def _launch_bwd(u, delta, A, B, C, D, delta_bias, x_chk, dout, delta_softplus, s
         du = torch.empty((batch, dim, L), device=dev, dtype=torch.float32)
         ddelta = torch.empty((batch, dim, L), device=dev, dtype=torch.float32)
     assert dout.stride(2) == 1 and dout.stride(1) == du.stride(1), "dout and du/ddelta must share the channel stride"
-    # accumulated with atomics across batch / channel tiles -> zero-filled here (header contract)
-    if dparams is None:
-        dA = torch.zeros((dim, N), device=dev, dtype=torch.float32)
-        dD = None if D is None else torch.zeros((dim,), device=dev, dtype=torch.float32)
-        dbias = None if delta_bias is None else torch.zeros((dim,), device=dev, dtype=torch.float32)
-    else:
-        dA, dD, dbias = dparams
-        assert dA.shape == (dim, N) and dA.is_contiguous() and dD.shape == (dim,) and dbias.shape == (dim,)
-    if dBC is None:
-        dB = torch.zeros((batch, G, N, L), device=dev, dtype=torch.float32)
-        dC = torch.zeros((batch, G, N, L), device=dev, dtype=torch.float32)
-    else:
-        dB, dC = dBC
-        assert dB.stride(3) == 1 and dC.stride(3) == 1 and dB.shape == (batch, G, N, L) == dC.shape
+    own_parts = parts is None
+    if own_parts:
+        S = dim * N + 2 * dim
+        parts = (torch.empty((batch, S), device=dev, dtype=torch.float32), 0, dim * N, dim * N + dim)
+    pbuf, oA, oD, ob = parts
+    assert pbuf.is_contiguous() and pbuf.shape[0] == batch
+    if dBC_dst is None:
+        dBC_dst = torch.empty((batch, G, 2 * N, L), device=dev, dtype=torch.float32)
+    assert dBC_dst.shape == (batch, G, 2 * N, L) and dBC_dst.stride(3) == 1
     a = _lib.ScanArgs()
     _fill_common(a, u, delta, A, B, C, D, delta_bias, delta_softplus)
     a.x_chk, a.dout = x_chk.data_ptr(), dout.data_ptr()
-    a.du, a.ddelta, a.dA, a.dB, a.dC = du.data_ptr(), ddelta.data_ptr(), dA.data_ptr(), dB.data_ptr(), dC.data_ptr()
-    a.dD, a.ddelta_bias = _ptr(dD), _ptr(dbias)
+    a.du, a.ddelta = du.data_ptr(), ddelta.data_ptr()
+    a.dA = pbuf.data_ptr() + 4 * oA
+    a.dD = None if D is None else pbuf.data_ptr() + 4 * oD
+    a.ddelta_bias = None if delta_bias is None else pbuf.data_ptr() + 4 * ob
+    a.dpar_sb = pbuf.stride(0)
     a.u_groups, a.u_map, a.rev_mask = shared
     a.dout_sb, a.dud_sb, a.o_sd = dout.stride(0), du.stride(0), du.stride(1)
     a.variant = _BWD_VARIANT
-    if dBC is not None:
-        a.dB_sb, a.dB_sg, a.dB_sn = dB.stride(0), dB.stride(1), dB.stride(2)
-        a.dC_sb, a.dC_sg, a.dC_sn = dC.stride(0), dC.stride(1), dC.stride(2)
+
+    def point_dBC(t, plane_stride):
+        a.dB, a.dC = t.data_ptr(), t.data_ptr() + 4 * N * t.stride(2)
+        a.dB_sb, a.dB_sg, a.dB_sn = t.stride(0), t.stride(1), t.stride(2)
+        a.dC_sb, a.dC_sg, a.dC_sn = t.stride(0), t.stride(1), t.stride(2)
+        a.dBC_sc = plane_stride
+
+    point_dBC(dBC_dst, 0)
+    plan = (ctypes.c_int32 * 8)()
+    lib = _lib.lib()
+    _lib.check(lib.mm_scan_plan(a, 1, plan), "mm_scan_plan")
+    W = plan[6]
+    planes = None
+    if W > 1:      # a direction is shared by W workgroups: one partial plane each, summed below
+        planes = _like_strided(dBC_dst, W)
+        point_dBC(planes[0], planes.stride(0))
     with _lib.device_guard(dev):
         t0 = KERNEL_TIMER.start()
-        rc = _lib.lib().mm_scan_bwd(a, _lib.raw_stream())
+        rc = lib.mm_scan_bwd(a, _lib.raw_stream())
         KERNEL_TIMER.stop("scan_bwd", t0, scan_bytes_bwd(batch, dim, L, N, G))
     _lib.check(rc, "mm_scan_bwd")
-    return du, ddelta, dA, dB, dC, dD, dbias
+    if planes is not None:
+        torch.sum(planes, dim=0, out=dBC_dst)
+    dA = dD = dbias = None
+    if own_parts:
+        sums = pbuf.sum(0)
+        dA = sums[:dim * N].view(dim, N)
+        dD = None if D is None else sums[dim * N:dim * N + dim]
+        dbias = None if delta_bias is None else sums[dim * N + dim:]
+    return du, ddelta, dA, dBC_dst[:, :, :N], dBC_dst[:, :, N:], dD, dbias
 
 
 def _prep(u, delta, A, B, C, D, delta_bias):
@@ -212,7 +251,7 @@ class SelectiveScanFn(torch.autograd.Function):
     """Autograd wrapper around mm_scan_fwd / mm_scan_bwd (the selective_scan_fn operator).
 
     Saved for backward: u, delta, A, B, C, D, delta_bias and the state checkpoints x_chk
-    (batch, dim, ceil(L/16), 16) that the forward kernel writes — the backward kernel recomputes the
+    (batch, ceil(L/16), dim, 16) that the forward kernel writes — the backward kernel recomputes the
     states of each 16-step chunk from them instead of storing all L x 16 states."""
 
     @staticmethod

@@ -75,11 +75,12 @@ def test_integration_md_binding_matches_the_header(tmp_path):
     assert got[0] == ctypes.sizeof(S)
     assert got[4:] == [getattr(S, n).offset for n in names]
     base, dbc, strided = got[1:4]
+    v18 = S.dpar_sb.offset
     lib = ns["lib"]
     a = S(struct_size=ctypes.sizeof(S), batch=1, dim=8, L=8, N=16, G=4)
     assert lib.mm_scan_fwd(ctypes.byref(a), None) == -1             # MM_ERR_NULL: sizes fine, operands missing
     # struct sizes: every layout the header ever ended at is accepted, anything else is MM_ERR_SHAPE before any other check
-    for sz, want in [(0, -2), (24, -2), (base, -1), (base + 8, -2), (dbc, -1), (strided, -1), (ctypes.sizeof(S) - 4, -2),
+    for sz, want in [(0, -2), (24, -2), (base, -1), (base + 8, -2), (dbc, -1), (strided, -1), (v18, -1), (ctypes.sizeof(S) - 4, -2),
                      (ctypes.sizeof(S), -1)]:
         a.struct_size = sz
         assert lib.mm_scan_fwd(ctypes.byref(a), None) == want, sz

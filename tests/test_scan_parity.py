@@ -148,11 +148,15 @@ def test_forward_options():
 
 @pytest.mark.parametrize("shape", [(2, 4, 8, 37), (1, 4, 24, 196), (2, 4, 96, 64), (1, 2, 5, 130), (3, 4, 32, 49),
                                    (1, 4, 200, 80)])
-@pytest.mark.parametrize("bwd_variant", [0, 1 << 24, 1 << 25, (1 << 24) | (3 << 16), (1 << 24) | (12 << 16), (1 << 25) | (2 << 16)],
-                         ids=["plan", "2states", "4states", "2states_3waves", "2states_12waves", "4states_2waves"])
+@pytest.mark.parametrize("bwd_variant", [0, 1 << 24, 1 << 25, (1 << 24) | (3 << 16), (1 << 24) | (12 << 16), (1 << 25) | (2 << 16),
+                                         (1 << 25) | (1 << 16) | (3 << 8), (1 << 24) | (2 << 16) | (2 << 8), (1 << 25) | (1 << 16) | (1 << 8),
+                                         (1 << 25) | (1 << 16) | (255 << 8)],
+                         ids=["plan", "2states", "4states", "2states_3waves", "2states_12waves", "4states_2waves",
+                              "4states_1wave_3passes", "2states_2waves_2passes", "4states_1wave_1pass", "4states_1wave_allpasses"])
 def test_backward_vs_oracle(shape, bwd_variant, monkeypatch):
-    """Both lane mappings of scan_bwd.hip (2 and 4 states per lane: variant bits 24 / 25) and several workgroup widths
-    (variant bits 16-23: one workgroup per direction with plain dB/dC stores, or several with atomics)."""
+    """Both lane mappings of scan_bwd.hip (2 and 4 states per lane: variant bits 24 / 25), several workgroup widths (variant
+    bits 16-23) and pass counts (bits 8-15: channel tiles a workgroup walks in turn; with every tile of a direction in ONE
+    workgroup dB/dC are plain stores + read-modify-writes, with several workgroups per direction they are partial planes)."""
     from medmamba_amd import selective_scan_interface as ssi
     monkeypatch.setattr(ssi, "_BWD_VARIANT", bwd_variant)
     _check_bwd(_make(*shape, seed=1 + sum(shape)))
@@ -338,3 +342,62 @@ def test_full_size_backward_properties(shape, monkeypatch):
             scale = max(1.0, float(a1.abs().max()))
             assert float((a4 - a1).abs().max()) <= 2e-4 * scale, (name, force)
         del r4
+
+
+@pytest.mark.parametrize("bwd_variant", [0, (1 << 25) | (1 << 16) | (2 << 8), (1 << 24) | (2 << 16) | (1 << 8)],
+                         ids=["plan", "4states_1wave_2passes", "2states_2waves_1pass"])
+def test_backward_is_bitwise_reproducible(bwd_variant, monkeypatch):
+    """VERDICT r2 item 7 / reference train.py:21-29 (deterministic training): the backward uses no atomics — dA / dD / dbias
+    through per-batch-item partial buffers, dB / dC in place or through per-workgroup partial planes, all summed in a fixed
+    order — so two runs give the same bits, whatever the plan (several workgroups per direction, several passes)."""
+    from medmamba_amd import selective_scan_interface as ssi
+    monkeypatch.setattr(ssi, "_BWD_VARIANT", bwd_variant)
+    dev = _dev()
+    args = [t.to(dev) for t in _make(3, 4, 200, 196, seed=21, contiguous_bc=True)]
+    u, delta, A, Bs, Cs, D, bias, dout = args
+    _, x_chk = ssi._launch_fwd(u, delta, A, Bs, Cs, D, bias, True, True)
+    plan = _plan_of(u, delta, A, Bs, Cs, backward=True, variant=bwd_variant)
+    if bwd_variant:
+        assert plan["W"] > 1 and (plan["passes"] > 1 or (bwd_variant >> 8) & 0xff == 1), plan
+    runs = []
+    for _ in range(3):
+        junk = torch.randn(1 << 20, device=dev)                      # move the allocator / the scheduler a little
+        r = ssi._launch_bwd(u, delta, A, Bs, Cs, D, bias, x_chk, dout, True)
+        torch.cuda.synchronize()
+        runs.append([t.clone() for t in r])
+        del junk
+    for r in runs[1:]:
+        for name, a, b in zip(["du", "ddelta", "dA", "dB", "dC", "dD", "dbias"], runs[0], r):
+            assert torch.equal(a, b), name
+
+
+def _plan_of(u, delta, A, Bs, Cs, backward, variant=0, det=True):
+    import ctypes
+    from medmamba_amd import _lib
+    from medmamba_amd import selective_scan_interface as ssi
+    a = _lib.ScanArgs()
+    ssi._fill_common(a, u, delta, A, Bs, Cs, None, None, True)
+    a.variant = variant
+    if det:
+        a.dpar_sb, a.dBC_sc = 1, 1
+    out = (ctypes.c_int32 * 8)()
+    assert _lib.lib().mm_scan_plan(a, int(backward), out) == 0
+    return dict(ns=out[0], waves=out[1], blocks=out[2], vec=out[3], lean=out[4], det=out[5], W=out[6], passes=out[7])
+
+
+def test_backward_plans_fill_the_chip():
+    """The launch plans of the backward for the benchmark shapes: one 12-wave workgroup per direction at the
+    56x56 stage of S (2 states per lane), 512 4-wave workgroups elsewhere, walking 1 / 3 / 6 channel tiles each at the 28x28 / 14x14 / 7x7 stages."""
+    dev = _dev()
+    mk = lambda b, d, L: torch.empty((b, d, L), device=dev)
+    for (b, H, L), want in {(64, 96, 3136): dict(ns=2, waves=12, blocks=256, W=1, passes=1),
+                            (64, 192, 784): dict(ns=4, waves=4, blocks=768, W=3, passes=1),
+                            (64, 384, 196): dict(ns=4, waves=4, blocks=512, W=2, passes=3),
+                            (64, 768, 49): dict(ns=4, waves=4, blocks=512, W=2, passes=6),
+                            (32, 128, 9216): dict(ns=2, waves=8, blocks=256, W=2, passes=1)}.items():
+        u = mk(b, 4 * H, L)
+        xd = torch.empty((b, 4, 35, L), device=dev)
+        p = _plan_of(u, u, torch.empty((4 * H, 16), device=dev), xd[:, :, 3:19], xd[:, :, 19:], backward=True)
+        for k, v in want.items():
+            assert p[k] == v, ((b, H, L), p)
+        assert p["det"] == 1
