@@ -44,6 +44,12 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md §Chip-level parameters)
+# Secondary ceiling of the scan kernels ("fp32 VALU / v_exp_f32 issue"): the irreducible VALU work per state-step —
+# forward v_mul, v_exp_f32, v_mul, v_fma, v_fma = 5 instructions; backward: recompute 4 + adjoint 10 + the second v_exp_f32 = 15,
+# counting a v_exp_f32 once — at the issue rate tools/ubench/valu_rate.cpp measures for that mix on a saturated SIMD (7.5 ns per
+# wavefront-state-step of 5 instructions), over the chip's 1024 SIMDs.  valu_floor_frac = that time / measured time.
+VALU_FLOOR_NS_PER_WAVE_STEP = {"scan_fwd": 7.5, "scan_bwd": 7.5 * 15 / 5}
+N_SIMD = 1024
 
 
 def cpu_baseline(size, res, nimg=32, mode="train"):
@@ -270,10 +276,13 @@ def main():
                  "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": tr, "kernel": tag,
                  "calls": d["calls"], "avg_us_per_call": round(1e3 * d["ms"] / d["calls"], 2),
                  "algorithmic_MB_per_call": round(d["bytes"] / d["calls"] / 1e6, 2)}
+            floor_ms = d["state_steps"] / 64.0 * VALU_FLOOR_NS_PER_WAVE_STEP[tag] / N_SIMD * 1e-6
+            r["valu_floor_frac"] = round(floor_ms / d["ms"], 4)
             i = ks_iso.get(tag)
             if i and i["ms"] > 0:       # same kernel, same shapes, nothing else on the GPU (see above)
                 r["achieved_alone"] = round(i["bytes"] / i["ms"] / 1e6, 1)
                 r["frac_alone"] = round(r["achieved_alone"] / HBM_PEAK_GBS, 4)
+                r["valu_floor_frac_alone"] = round(i["state_steps"] / 64.0 * VALU_FLOOR_NS_PER_WAVE_STEP[tag] / N_SIMD * 1e-6 / i["ms"], 4)
             return r
 
         what = "fwd+bwd" if args.mode == "train" else "fwd"

@@ -555,18 +555,16 @@ int scan_bwd_launch(const mm_scan_args* a, hipStream_t stream, int32_t* plan_out
     // 96x96 stage at 4 states per lane: 4.87 ms with 512 x 2 waves, 3.24 ms with 256 x 4, 4.25 ms with 128 x 8); never more
     // when a direction spans several: at the ONE barrier per tile the whole workgroup waits for its slowest wave, and two
     // 4-wave workgroups per CU cover each other's waits (measured at stages 2-4: 0.62 vs 0.76 / 0.80 ms for 6 / 8 waves).
-    // Round 3: the grid is sized to what is resident at once (2 workgroups per CU = 512) and every workgroup walks `npass`
-    // channel tiles in turn, instead of 1.5 - 3 rounds of single-tile workgroups: no partially filled last round, B/C of a
-    // direction fetched by `ncw` workgroups instead of waves_needed / 4, and dB / dC shared by 1 - 4 workgroups only.
     const int wpw = forced > 0 ? (forced > wmax ? wmax : forced) : (ns == 4 ? 4 : 8);
     const int tiles = (waves_needed + wpw - 1) / wpw;         // channel tiles of wpw waves per direction
     long want = (512 + pairs - 1) / pairs;                    // workgroups per direction that fill the chip
     if (want < 1) want = 1;
-    // the largest pass count that divides the tiles evenly (every workgroup of a direction walks the same number) and still
-    // leaves `want` workgroups per direction
+    // One pass by default: measured (tools/bench_scan_bwd.py, S, Bz = 64, kernel alone) 0.280 vs 0.290 ms at the 14x14 stage
+    // and 0.177 vs 0.187 ms at 7x7 for 1536 / 3072 single-tile workgroups against 512 workgroups walking 3 / 6 tiles — a pass
+    // switch drains the whole workgroup, a finished single-tile workgroup is replaced while its neighbour on the CU keeps
+    // computing.  Several passes (variant bits 8-15) remain for callers that want fewer dB / dC partial planes.
+    (void)want;
     npass = 1;
-    for (int q = 2; q <= tiles; ++q)
-      if (tiles % q == 0 && tiles / q >= want) npass = q;
     if (forced_pass > 0) { npass = forced_pass < tiles ? forced_pass : tiles; }
     ncw = (tiles + npass - 1) / npass;
     waves = (waves_needed + ncw * npass - 1) / (ncw * npass);

@@ -25,7 +25,7 @@ import torch.nn.functional as F
 import torch.utils.checkpoint as checkpoint
 
 from . import _lib
-from .ops import (PointwiseConvFn, block_split, block_split_infer, bn_relu_train, conv2d_bias, nchw_ln_rows,
+from .ops import (PointwiseConvFn, block_split, deferred_bn_counters, block_split_infer, bn_relu_train, conv2d_bias, nchw_ln_rows,
                   nchw_ln_rows_supported, patch_merge_ln, patch_merge_ln_supported, dwconv_silu_cross, in_proj_cf, out_proj_cf, shuffle_residual,
                   ss2d_conv_core, ss2d_core)
 from .selective_scan_interface import CROSS_SCAN_K_OF_G, cross_scan_fn, selective_scan_fn
@@ -690,9 +690,10 @@ class VSSM(nn.Module):
     def forward_backbone(self, x):
         drawn = self._draw_drop_path(x.shape[0], x.device) if (self.training and x.is_cuda) else []
         try:
-            x = self.pos_drop(self.patch_embed(x))
-            for layer in self.layers:
-                x = layer(x)
+            with deferred_bn_counters():          # one multi-tensor add for all BatchNorm step counters of this forward
+                x = self.pos_drop(self.patch_embed(x))
+                for layer in self.layers:
+                    x = layer(x)
         finally:
             for b in drawn:
                 b._dp_factor = None

@@ -766,11 +766,35 @@ class BNReluFn(torch.autograd.Function):
         return dx, dgb[0], dgb[1], None, None, None, None, None
 
 
+_DEFERRED_COUNTERS = None      # list while a caller batches the BatchNorm step counters of a whole forward (VSSM.forward_backbone)
+
+
+class deferred_bn_counters:
+    """Inside this context the `num_batches_tracked += 1` of every BatchNorm that bn_relu_train runs is collected and applied
+    by ONE multi-tensor add on exit (42 one-element launches per MedMamba-S step otherwise).  Only for the default
+    momentum semantics; a BatchNorm with momentum=None needs its counter at once and keeps the immediate add."""
+
+    def __enter__(self):
+        global _DEFERRED_COUNTERS
+        self.prev, _DEFERRED_COUNTERS = _DEFERRED_COUNTERS, []
+        return self
+
+    def __exit__(self, *exc):
+        global _DEFERRED_COUNTERS
+        pending, _DEFERRED_COUNTERS = _DEFERRED_COUNTERS, self.prev
+        if pending:
+            torch._foreach_add_(pending, 1)
+        return False
+
+
 def bn_relu_train(x, bn, relu):
     """`bn` (an nn.BatchNorm2d in training mode, affine, default momentum semantics) applied to x, optionally followed by
     ReLU, through BNReluFn; num_batches_tracked advances as in the module's own forward."""
     if bn.track_running_stats and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
+        if _DEFERRED_COUNTERS is not None and bn.momentum is not None:
+            _DEFERRED_COUNTERS.append(bn.num_batches_tracked)
+        else:
+            bn.num_batches_tracked.add_(1)
         momentum = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
     else:
         momentum = 0.0 if bn.momentum is None else bn.momentum

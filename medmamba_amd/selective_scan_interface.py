@@ -25,7 +25,7 @@ class _KernelTimer:
 
     def __init__(self):
         self.enabled = False
-        self.records = []          # (tag, start_event, end_event, algorithmic_bytes)
+        self.records = []          # (tag, start_event, end_event, algorithmic_bytes, state_steps)
 
     def start(self):
         if not self.enabled:
@@ -34,21 +34,22 @@ class _KernelTimer:
         ev.record()
         return ev
 
-    def stop(self, tag, start, nbytes):
+    def stop(self, tag, start, nbytes, nsteps=0):
         if start is None:
             return
         end = torch.cuda.Event(enable_timing=True)
         end.record()
-        self.records.append((tag, start, end, nbytes))
+        self.records.append((tag, start, end, nbytes, nsteps))
 
     def summary(self):
         """{tag: dict(calls, ms, bytes)} — call only after torch.cuda.synchronize()."""
         out = {}
-        for tag, s, e, nb in self.records:
-            d = out.setdefault(tag, dict(calls=0, ms=0.0, bytes=0))
+        for tag, s, e, nb, ns in self.records:
+            d = out.setdefault(tag, dict(calls=0, ms=0.0, bytes=0, state_steps=0))
             d["calls"] += 1
             d["ms"] += s.elapsed_time(e)
             d["bytes"] += nb
+            d["state_steps"] += ns
         return out
 
 
@@ -147,7 +148,7 @@ def _launch_fwd(u, delta, A, B, C, D, delta_bias, delta_softplus, want_chk, vari
     with _lib.device_guard(u.device):
         t0 = KERNEL_TIMER.start()
         rc = _lib.lib().mm_scan_fwd(a, _lib.raw_stream())
-        KERNEL_TIMER.stop("scan_fwd", t0, scan_bytes_fwd(batch, dim, L, A.shape[1], B.shape[1]))
+        KERNEL_TIMER.stop("scan_fwd", t0, scan_bytes_fwd(batch, dim, L, A.shape[1], B.shape[1]), batch * dim * L * A.shape[1])
     _lib.check(rc, "mm_scan_fwd")
     return out, x_chk
 
@@ -226,7 +227,7 @@ def _launch_bwd(u, delta, A, B, C, D, delta_bias, x_chk, dout, delta_softplus, s
     with _lib.device_guard(dev):
         t0 = KERNEL_TIMER.start()
         rc = lib.mm_scan_bwd(a, _lib.raw_stream())
-        KERNEL_TIMER.stop("scan_bwd", t0, scan_bytes_bwd(batch, dim, L, N, G))
+        KERNEL_TIMER.stop("scan_bwd", t0, scan_bytes_bwd(batch, dim, L, N, G), batch * dim * L * N)
     _lib.check(rc, "mm_scan_bwd")
     if planes is not None:
         torch.sum(planes, dim=0, out=dBC_dst)

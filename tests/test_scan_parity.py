@@ -387,13 +387,13 @@ def _plan_of(u, delta, A, Bs, Cs, backward, variant=0, det=True):
 
 def test_backward_plans_fill_the_chip():
     """The launch plans of the backward for the benchmark shapes: one 12-wave workgroup per direction at the
-    56x56 stage of S (2 states per lane), 512 4-wave workgroups elsewhere, walking 1 / 3 / 6 channel tiles each at the 28x28 / 14x14 / 7x7 stages."""
+    56x56 stage of S (2 states per lane), 512 single-pass 4-wave workgroups elsewhere (3 / 6 / 12 per direction at the 28x28 / 14x14 / 7x7 stages: dB / dC partial planes)."""
     dev = _dev()
     mk = lambda b, d, L: torch.empty((b, d, L), device=dev)
     for (b, H, L), want in {(64, 96, 3136): dict(ns=2, waves=12, blocks=256, W=1, passes=1),
                             (64, 192, 784): dict(ns=4, waves=4, blocks=768, W=3, passes=1),
-                            (64, 384, 196): dict(ns=4, waves=4, blocks=512, W=2, passes=3),
-                            (64, 768, 49): dict(ns=4, waves=4, blocks=512, W=2, passes=6),
+                            (64, 384, 196): dict(ns=4, waves=4, blocks=1536, W=6, passes=1),
+                            (64, 768, 49): dict(ns=4, waves=4, blocks=3072, W=12, passes=1),
                             (32, 128, 9216): dict(ns=2, waves=8, blocks=256, W=2, passes=1)}.items():
         u = mk(b, 4 * H, L)
         xd = torch.empty((b, 4, 35, L), device=dev)

@@ -65,7 +65,7 @@ def main():
                         runf()
                     torch.cuda.synchronize()
                     ssi.KERNEL_TIMER.enabled = False
-                    ts = sorted(s.elapsed_time(e) for tag, s, e, nb in ssi.KERNEL_TIMER.records if tag == "scan_fwd")
+                    ts = sorted(s.elapsed_time(e) for tag, s, e, *_ in ssi.KERNEL_TIMER.records if tag == "scan_fwd")
                     med = ts[len(ts) // 2]
                     print(json.dumps(dict(model=model, batch=Bz, D=D, L=L, layout="cm" if cm else "bm", fwd_variant=hex(fv), chk=chk,
                                           fwd_kernel_ms=round(med, 4), frac_8TBs=round(fb / med / 8e9, 4))), flush=True)
@@ -86,7 +86,7 @@ def main():
                     run()
                 torch.cuda.synchronize()
                 ssi.KERNEL_TIMER.enabled = False
-                ts = sorted(s.elapsed_time(e) for tag, s, e, nb in ssi.KERNEL_TIMER.records if tag == "scan_bwd")
+                ts = sorted(s.elapsed_time(e) for tag, s, e, *_ in ssi.KERNEL_TIMER.records if tag == "scan_bwd")
                 med = ts[len(ts) // 2]
             except Exception as e:  # noqa
                 print(f"D={D} L={L} variant={v:#x}: {e}")

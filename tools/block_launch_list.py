@@ -17,18 +17,19 @@ for _ in range(3):
     blk.zero_grad(set_to_none=True); blk(x).sum().backward()
 torch.cuda.synchronize()
 from torch.profiler import profile, ProfilerActivity
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
     blk.zero_grad(set_to_none=True)
     y = blk(x); y.backward(torch.ones_like(y)); torch.cuda.synchronize()
 rows = []
 for e in prof.events():
     for k in e.kernels:
-        rows.append((e.time_range.start, e.name, k.name, k.duration))
+        fr = [f for f in (e.stack or []) if "medmamba_amd" in f]
+        rows.append((e.time_range.start, e.name, k.name, k.duration, (fr[0].split("medmamba_amd/")[-1] if fr else "")))
 rows.sort()
 seen = set(); n = 0; tot = 0.0
-for t, op, kn, us in rows:
+for t, op, kn, us, where in rows:
     key = (t, kn)
     if key in seen: continue
     seen.add(key); n += 1; tot += us
-    print(f"{n:3d} {us:7.1f} us  {op[:34]:<34} {kn[:90]}")
+    print(f"{n:3d} {us:7.1f} us  {op[:30]:<30} {where[:44]:<44} {kn[:60]}")
 print("launches", n, "device us", round(tot, 1))
