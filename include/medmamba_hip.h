@@ -275,8 +275,23 @@ int mm_nchw_ln_rows_bwd(const float* dy, const float* x, const float* gamma, con
 int mm_bn_splits(int batch, int C, int HW);
 int mm_bn_relu_fwd(const float* x, const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
                    float* running_var, float* y, float* mean, float* rstd, float* ws, int relu, int batch, int C, int HW, void* stream);
+/* The same forward with the batch statistics already available as `nparts` partials per channel, partials[(q*C + c)*3 + (0: count,
+ * 1: mean, 2: M2 = sum of squared deviations from that mean)] — what mm_conv3x3_fwd emits for its output: one pass (apply) only. */
+int mm_bn_relu_fwd_stats(const float* x, const float* partials, int nparts, const float* gamma, const float* beta, float eps,
+                         float momentum, float* running_mean, float* running_var, float* y, float* mean, float* rstd, int relu,
+                         int batch, int C, int HW, void* stream);
 int mm_bn_relu_bwd(const float* dy, const float* x, const float* gamma, const float* beta, const float* mean, const float* rstd,
                    float* dx, float* dgamma, float* dbeta, float* ws, int relu, int batch, int C, int HW, void* stream);
+
+/* Dense 3x3 convolution, padding 1, stride 1, of the conv branch (MedMamba.py:339, 342), forward, fp32 on the matrix cores:
+ *   y[b,k,h,w] = bias[k] + sum_{c,r,s} w[k,c,r,s] * x'[b,c,h+r-1,w+s-1];  x, y contiguous NCHW, w (K, C, 3, 3), bias (K) or NULL.
+ *   in_affine = [scale C | shift C] or NULL: x' = x*scale[c] + shift[c] (then ReLU if in_relu) inside the image, 0 in the padding —
+ *   an eval-mode / already-normalised BatchNorm (+ReLU) in front of the convolution, applied while the input is staged.
+ *   stats (optional): (mm_conv3x3_fwd_tiles(batch, H, W), K, 3) floats: per position tile and output channel (count, mean, M2) of
+ *   the outputs (bias included) — the statistics pass of a training-mode BatchNorm that follows (mm_bn_relu_fwd_stats). */
+int mm_conv3x3_fwd_tiles(int batch, int H, int W);
+int mm_conv3x3_fwd(const float* x, const float* w, const float* bias, const float* in_affine, int in_relu, float* y, float* stats,
+                   int batch, int C, int K, int H, int W, void* stream);
 
 /* SS2D parameters (MedMamba.py:150-175) -> one buffer in kernel direction order, A = -exp(A_logs) (MedMamba.py:271):
  *   x_proj_w (4, C, D), dt_w (4, D, R), dt_b (4, D), A_logs (4*D, N), Ds (4*D) in the reference's direction order

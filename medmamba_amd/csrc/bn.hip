@@ -30,7 +30,7 @@ __device__ __forceinline__ float block_sum(float v, float* red) {     // sum ove
 }
 
 // slice s of the batch: images [s*nb, min((s+1)*nb, batch))
-struct BnGeom { int batch, C, HW, nb, S; };
+struct BnGeom { int batch, C, HW, nb, S, SP; };   // SP = number of statistics partials per channel (= S unless they come from elsewhere)
 
 // partial[(s*C + c)*3 + (0: count, 1: mean, 2: M2)]
 __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, float* __restrict__ partial, BnGeom g) {
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
 // merge the S partials of channel c (Chan et al.): every thread computes the same few values
 __device__ __forceinline__ void bn_merge(const float* __restrict__ partial, int c, const BnGeom& g, float& n, float& mean, float& m2) {
   n = 0.f; mean = 0.f; m2 = 0.f;
-  for (int s = 0; s < g.S; ++s) {
+  for (int s = 0; s < g.SP; ++s) {
     const float* o = partial + ((int64_t)s * g.C + c) * 3;
     const float nb = o[0], mb = o[1], Mb = o[2];
     const float nn = n + nb, d = mb - mean;
@@ -206,7 +206,7 @@ inline BnGeom bn_geom(int batch, int C, int HW) {
   while (S > 1 && (int64_t)((batch + S - 1) / S) * per_img < 16 * 1024) --S;
   if (S < 1) S = 1;
   BnGeom g;
-  g.batch = batch; g.C = C; g.HW = HW; g.nb = (batch + S - 1) / S; g.S = (batch + g.nb - 1) / g.nb;
+  g.batch = batch; g.C = C; g.HW = HW; g.nb = (batch + S - 1) / S; g.S = (batch + g.nb - 1) / g.nb; g.SP = g.S;
   return g;
 }
 }  // namespace
@@ -225,6 +225,19 @@ int mm_bn_relu_fwd(const float* x, const float* gamma, const float* beta, float 
   hipLaunchKernelGGL(bn_stats_kernel, dim3(C * g.S), dim3(256), 0, s, x, ws, g);
   hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3(C * g.S), dim3(256), 0, s, x, ws, gamma, beta, eps, momentum, running_mean, running_var, y, mean,
                      rstd, relu, g);
+  return (int)hipGetLastError();
+}
+
+int mm_bn_relu_fwd_stats(const float* x, const float* partials, int nparts, const float* gamma, const float* beta, float eps,
+                         float momentum, float* running_mean, float* running_var, float* y, float* mean, float* rstd, int relu,
+                         int batch, int C, int HW, void* stream) {
+  if (!x || !partials || !gamma || !beta || !y || !mean || !rstd) return MM_ERR_NULL;
+  if (batch <= 0 || C <= 0 || HW <= 0 || nparts <= 0) return MM_ERR_SHAPE;
+  if ((int64_t)batch * HW < 2) return MM_ERR_SHAPE;
+  BnGeom g = bn_geom(batch, C, HW);
+  g.SP = nparts;
+  hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3(C * g.S), dim3(256), 0, (hipStream_t)stream, x, partials, gamma, beta, eps, momentum,
+                     running_mean, running_var, y, mean, rstd, relu, g);
   return (int)hipGetLastError();
 }
 

@@ -24,7 +24,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 import torch.utils.checkpoint as checkpoint
 
-from . import _lib
+from . import _lib, ops
 from .ops import (PointwiseConvFn, block_split, deferred_bn_counters, block_split_infer, bn_relu_train, conv2d_bias, nchw_ln_rows,
                   nchw_ln_rows_supported, patch_merge_ln, patch_merge_ln_supported, dwconv_silu_cross, in_proj_cf, out_proj_cf, shuffle_residual,
                   ss2d_conv_core, ss2d_core)
@@ -72,10 +72,25 @@ def _conv_branch(mods, x):
     i = 0
     while i < len(mods):
         m = mods[i]
+        own_bn = lambda bn, t: (_OWN_BN and type(bn) is nn.BatchNorm2d and t.is_cuda and bn.affine and t.dtype == torch.float32
+                                and t.dim() == 4 and (bn.training or not bn.track_running_stats))
         if isinstance(m, nn.Conv2d) and x.is_cuda:
-            x = PointwiseConvFn.apply(x, m.weight, m.bias) if _is_pointwise(m) else conv2d_bias(x, m)
-        elif (_OWN_BN and type(m) is nn.BatchNorm2d and x.is_cuda and m.affine and x.dtype == torch.float32 and x.dim() == 4
-              and (m.training or not m.track_running_stats)):
+            if _is_pointwise(m):
+                x = PointwiseConvFn.apply(x, m.weight, m.bias)
+            elif ops.own_conv3x3_ok(x, m):
+                # our MFMA conv: bias in its epilogue, and — when one of our BatchNorms follows — that BatchNorm's statistics
+                # pass too (the BatchNorm then only applies)
+                nxt = mods[i + 1] if i + 1 < len(mods) else None
+                if nxt is not None and own_bn(nxt, x):
+                    x, partials = ops.Conv3x3Fn.apply(x, m.weight, m.bias, True)
+                    relu = i + 2 < len(mods) and type(mods[i + 2]) is nn.ReLU
+                    x = bn_relu_train(x, nxt, relu, partials)
+                    i += 2 if relu else 1
+                else:
+                    x = ops.Conv3x3Fn.apply(x, m.weight, m.bias, False)
+            else:
+                x = conv2d_bias(x, m)
+        elif own_bn(m, x):
             # training-mode BatchNorm through our kernels; a directly following nn.ReLU is folded into them
             relu = i + 1 < len(mods) and type(mods[i + 1]) is nn.ReLU
             x = bn_relu_train(x, m, relu)

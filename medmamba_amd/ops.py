@@ -721,13 +721,58 @@ def nchw_ln_rows(x, gamma, beta, eps):
     return NchwLNRowsFn.apply(x, gamma, beta, eps)
 
 
+_OWN_CONV = os.environ.get("MM_OWN_CONV", "0") == "1"     # dense 3x3 convs of the conv branch (forward) through csrc/conv.hip
+
+
+class Conv3x3Fn(torch.autograd.Function):
+    """nn.Conv2d(C, K, 3, padding=1) forward through mm_conv3x3_fwd (fp32 MFMA implicit GEMM on NCHW, bias in the epilogue);
+    with want_stats the kernel also emits the per-channel (count, mean, M2) partials of its output — the statistics pass of the
+    training-mode BatchNorm that follows (BNReluFn(partials=...)).  The backward is MIOpen's (data and weight gradient) plus
+    the channel-sum bias gradient, exactly as ConvBiasFn."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, want_stats):
+        x, w = x.float().contiguous(), w.float().contiguous()
+        b = None if b is None else b.float().contiguous()
+        B, C, H, W = x.shape
+        K = w.shape[0]
+        lib = _lib.lib()
+        y = torch.empty((B, K, H, W), device=x.device, dtype=torch.float32)
+        stats = torch.empty((lib.mm_conv3x3_fwd_tiles(B, H, W), K, 3), device=x.device, dtype=torch.float32) if want_stats else None
+        with _lib.device_guard(x.device):
+            rc = lib.mm_conv3x3_fwd(x.data_ptr(), w.data_ptr(), None if b is None else b.data_ptr(), None, 0, y.data_ptr(),
+                                    None if stats is None else stats.data_ptr(), B, C, K, H, W, _stream())
+        _lib.check(rc, "mm_conv3x3_fwd")
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        if stats is None:
+            return y
+        ctx.mark_non_differentiable(stats)
+        return y, stats
+
+    @staticmethod
+    def backward(ctx, dy, dstats=None):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx, dw, _ = torch.ops.aten.convolution_backward(dy, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                                        [ctx.needs_input_grad[0], ctx.needs_input_grad[1], False])
+        db = _bias_grad(dy) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return dx, dw, db, None
+
+
+def own_conv3x3_ok(x, conv):
+    return (_OWN_CONV and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and conv.kernel_size == (3, 3)
+            and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1
+            and conv.padding_mode == "zeros")
+
+
 class BNReluFn(torch.autograd.Function):
     """Training-mode nn.BatchNorm2d (+ the nn.ReLU behind it when relu=True) on contiguous NCHW tensors — the conv branch's
     BN2+ReLU / BN3+ReLU / BN1 (MedMamba.py:338-344).  Updates running_mean / running_var in place like the module does; the
     caller advances num_batches_tracked."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, relu):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, relu, partials=None):
         x = x.float().contiguous()
         gamma, beta = gamma.float().contiguous(), beta.float().contiguous()
         B, C = x.shape[0], x.shape[1]
@@ -736,13 +781,22 @@ class BNReluFn(torch.autograd.Function):
         lib = _lib.lib()
         y = torch.empty_like(x)
         stats = torch.empty((2, C), device=dev, dtype=torch.float32)
-        ws = torch.empty((3 * C * lib.mm_bn_splits(B, C, HW),), device=dev, dtype=torch.float32)
-        with _lib.device_guard(dev):
-            rc = lib.mm_bn_relu_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), float(eps), float(momentum),
-                                    None if running_mean is None else running_mean.data_ptr(),
-                                    None if running_var is None else running_var.data_ptr(), y.data_ptr(), stats[0].data_ptr(),
-                                    stats[1].data_ptr(), ws.data_ptr(), int(bool(relu)), B, C, HW, _stream())
-        _lib.check(rc, "mm_bn_relu_fwd")
+        rm = None if running_mean is None else running_mean.data_ptr()
+        rv = None if running_var is None else running_var.data_ptr()
+        if partials is not None:       # batch statistics already produced by the kernel that wrote x (mm_conv3x3_fwd): apply only
+            assert partials.is_contiguous() and partials.shape[1:] == (C, 3)
+            with _lib.device_guard(dev):
+                rc = lib.mm_bn_relu_fwd_stats(x.data_ptr(), partials.data_ptr(), partials.shape[0], gamma.data_ptr(), beta.data_ptr(),
+                                              float(eps), float(momentum), rm, rv, y.data_ptr(), stats[0].data_ptr(),
+                                              stats[1].data_ptr(), int(bool(relu)), B, C, HW, _stream())
+            _lib.check(rc, "mm_bn_relu_fwd_stats")
+        else:
+            ws = torch.empty((3 * C * lib.mm_bn_splits(B, C, HW),), device=dev, dtype=torch.float32)
+            with _lib.device_guard(dev):
+                rc = lib.mm_bn_relu_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), float(eps), float(momentum), rm, rv,
+                                        y.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), ws.data_ptr(), int(bool(relu)),
+                                        B, C, HW, _stream())
+            _lib.check(rc, "mm_bn_relu_fwd")
         ctx.save_for_backward(x, gamma, beta, stats)
         ctx.relu = bool(relu)
         return y
@@ -763,7 +817,7 @@ class BNReluFn(torch.autograd.Function):
                                     stats[1].data_ptr(), dx.data_ptr(), dgb[0].data_ptr(), dgb[1].data_ptr(), ws.data_ptr(),
                                     int(ctx.relu), B, C, HW, _stream())
         _lib.check(rc, "mm_bn_relu_bwd")
-        return dx, dgb[0], dgb[1], None, None, None, None, None
+        return dx, dgb[0], dgb[1], None, None, None, None, None, None
 
 
 _DEFERRED_COUNTERS = None      # list while a caller batches the BatchNorm step counters of a whole forward (VSSM.forward_backbone)
@@ -787,7 +841,7 @@ class deferred_bn_counters:
         return False
 
 
-def bn_relu_train(x, bn, relu):
+def bn_relu_train(x, bn, relu, partials=None):
     """`bn` (an nn.BatchNorm2d in training mode, affine, default momentum semantics) applied to x, optionally followed by
     ReLU, through BNReluFn; num_batches_tracked advances as in the module's own forward."""
     if bn.track_running_stats and bn.num_batches_tracked is not None:
@@ -799,7 +853,7 @@ def bn_relu_train(x, bn, relu):
     else:
         momentum = 0.0 if bn.momentum is None else bn.momentum
     rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
-    y = BNReluFn.apply(x, bn.weight, bn.bias, rm, rv, bn.eps, momentum, relu)
+    y = BNReluFn.apply(x, bn.weight, bn.bias, rm, rv, bn.eps, momentum, relu, partials)
     if rm is not None:
         # the kernel updated the running statistics through raw pointers: bump their version counters like an in-place torch
         # op would, so that anything keyed on them (SS_Conv_SSM._eval_fold) sees the change even if only the BatchNorm modules

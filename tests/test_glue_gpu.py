@@ -521,3 +521,77 @@ def test_small_planes_ignore_the_strip_knob():
     for H, W in [(14, 14), (7, 7), (16, 16), (1, 200), (4, 64)]:
         assert lib.mm_dwconv_silu_cross_strips(H, W) == 1
     assert lib.mm_dwconv_silu_cross_strips(56, 56) >= 1 and lib.mm_dwconv_silu_cross_strips(96, 96) == 3
+
+
+@pytest.mark.parametrize("shape", [(64, 192, 192, 14, 14), (2, 5, 7, 6, 9), (3, 48, 48, 56, 56), (5, 384, 384, 7, 7), (1, 8, 64, 1, 1),
+                                   (2, 70, 130, 11, 3)])
+@pytest.mark.parametrize("mode", ["plain", "affine_relu", "nobias"])
+def test_own_conv3x3_forward_vs_fp64(shape, mode):
+    """csrc/conv.hip (fp32 MFMA implicit-GEMM 3x3 conv, MedMamba.py:339, 342): output against an fp64 convolution, the optional
+    input affine + ReLU (a BatchNorm folded in front, zero padding AFTER it), and the (count, mean, M2) partials of the epilogue
+    merged by mm_bn_relu_fwd_stats against torch.nn.BatchNorm2d on the same conv output."""
+    from medmamba_amd import _lib
+    B, C, K, H, W = shape
+    g = torch.Generator(device=DEV).manual_seed(sum(shape))
+    x = torch.randn(B, C, H, W, device=DEV, generator=g)
+    w = torch.randn(K, C, 3, 3, device=DEV, generator=g) / (3.0 * C ** 0.5)
+    b = None if mode == "nobias" else torch.randn(K, device=DEV, generator=g)
+    aff = torch.cat([torch.rand(C, device=DEV, generator=g) + 0.5, torch.randn(C, device=DEV, generator=g) * 0.3]) if mode == "affine_relu" else None
+    lib = _lib.lib()
+    y = torch.empty(B, K, H, W, device=DEV)
+    stats = torch.empty(lib.mm_conv3x3_fwd_tiles(B, H, W), K, 3, device=DEV)
+    rc = lib.mm_conv3x3_fwd(x.data_ptr(), w.data_ptr(), None if b is None else b.data_ptr(), None if aff is None else aff.data_ptr(),
+                            int(aff is not None), y.data_ptr(), stats.data_ptr(), B, C, K, H, W, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    xin = x.double()
+    if aff is not None:
+        xin = torch.relu(xin * aff[:C].double()[None, :, None, None] + aff[C:].double()[None, :, None, None])
+    ref = torch.nn.functional.conv2d(xin.cpu(), w.double().cpu(), None if b is None else b.double().cpu(), padding=1)
+    err = float((y.cpu().double() - ref).abs().max())
+    assert err <= 2e-5 * max(1.0, float(ref.abs().max())), err
+    # statistics partials -> BatchNorm apply; reference: torch's training-mode BatchNorm2d + ReLU on OUR conv output
+    if B * H * W >= 2:
+        bn = torch.nn.BatchNorm2d(K).to(DEV).train()
+        with torch.no_grad():
+            bn.weight.copy_(torch.randn(K, device=DEV, generator=g)); bn.bias.copy_(torch.randn(K, device=DEV, generator=g) * 0.2)
+        want = torch.relu(bn(y))
+        got = torch.empty_like(y)
+        mean, rstd = torch.empty(K, device=DEV), torch.empty(K, device=DEV)
+        rm, rv = torch.zeros(K, device=DEV), torch.ones(K, device=DEV)
+        rc = lib.mm_bn_relu_fwd_stats(y.data_ptr(), stats.data_ptr(), stats.shape[0], bn.weight.data_ptr(), bn.bias.data_ptr(), bn.eps, 0.1,
+                                      rm.data_ptr(), rv.data_ptr(), got.data_ptr(), mean.data_ptr(), rstd.data_ptr(), 1, B, K, H * W,
+                                      torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+        assert float((got - want).abs().max()) <= 1e-4 * max(1.0, float(want.abs().max()))
+        assert float((rm - bn.running_mean).abs().max()) <= 1e-5 * max(1.0, float(bn.running_mean.abs().max()))
+        assert float((rv - bn.running_var).abs().max()) <= 1e-4 * max(1.0, float(bn.running_var.abs().max()))
+
+
+def test_own_conv_branch_matches_miopen_branch(monkeypatch):
+    """MM_OWN_CONV=1: a block's conv branch with our forward convs (statistics in their epilogue) against the MIOpen route,
+    forward and all gradients, on the reference block fixture's weights."""
+    from medmamba_amd import modules, ops
+    from conftest import load_golden, split_sd
+    fx = load_golden("block_c16.npz")
+    blk = modules.SS_Conv_SSM(hidden_dim=16, drop_path=0.0, norm_layer=torch.nn.LayerNorm)
+    blk.load_state_dict(split_sd(fx))
+    blk.to(DEV).train()
+    x = torch.from_numpy(fx["x"]).to(DEV)
+    res = {}
+    for own in (False, True):
+        monkeypatch.setattr(ops, "_OWN_CONV", own)
+        blk.load_state_dict({k: v.to(DEV) for k, v in split_sd(fx).items()})        # same running statistics at the start
+        blk.zero_grad(set_to_none=True)
+        xi = x.clone().requires_grad_()
+        y = blk(xi)
+        (y * y).mean().backward()
+        res[own] = (y.detach().clone(), xi.grad.clone(), {k: p.grad.clone() for k, p in blk.named_parameters()},
+                    {k: v.clone() for k, v in blk.state_dict().items() if "running" in k})
+    assert float((res[True][0] - res[False][0]).abs().max()) <= 2e-5 * max(1.0, float(res[False][0].abs().max()))
+    assert float((res[True][1] - res[False][1]).abs().max()) <= 1e-4 * max(1e-3, float(res[False][1].abs().max()))
+    for k, v in res[False][2].items():
+        if k.endswith("conv33conv33conv11.1.bias") or k.endswith("conv33conv33conv11.4.bias"):
+            continue                                                             # exact-zero true gradient: rounding noise
+        assert float((res[True][2][k] - v).abs().max()) <= 2e-4 * max(1e-3, float(v.abs().max())), k
+    for k, v in res[False][3].items():
+        assert float((res[True][3][k] - v).abs().max()) <= 1e-5 * max(1.0, float(v.abs().max())), k
