@@ -313,8 +313,9 @@ int mm_ss2d_pack_bwd(const float* dpacked, const float* packed, const float* par
 int mm_ss2d_pack_parts_size(int D, int C, int R, int N);
 
 /* Bias gradient of the conv branch's convolutions (MedMamba.py:338-346): out[c] = sum over batch and positions of the
- * contiguous NCHW tensor x (batch, C, HW).  When mm_channel_sum_nchw_split(batch, C) > 1 the batch is split over several
- * workgroups per channel that add with atomics: the caller zero-fills out (C floats) first. */
+ * contiguous NCHW tensor x (batch, C, HW).  When S = mm_channel_sum_nchw_split(batch, C) > 1 the batch is split over S
+ * workgroups per channel and `out` receives S rows of C partial sums (S*C floats, plain stores — no atomics since ABI 19);
+ * the caller adds the rows. */
 int mm_channel_sum_nchw_split(int batch, int C);
 int mm_channel_sum_nchw(const float* x, float* out, int batch, int C, int HW, void* stream);
 

@@ -660,9 +660,9 @@ __global__ __launch_bounds__(256) void ln_gate_bwd_kernel(const float* __restric
   c2 = pos_sum<PW>(c2) / D;
   float* dmp = dm + (int64_t)b * dm_sb + p;
   float* dzp = dz + (int64_t)b * dz_sb + p;
-  extern __shared__ float sred[];                       // [2*D]: dgamma | dbeta of this workgroup (4 waves add into it)
-  for (int i = threadIdx.x; i < 2 * D; i += blockDim.x) sred[i] = 0.f;
-  __syncthreads();
+  extern __shared__ float sred[];                       // [4 waves][2*D]: dgamma | dbeta, one row per wave (plain stores: every
+                                                        // (wave, d) is written exactly once), summed in wave order below — no LDS
+                                                        // float atomics, so the result does not depend on the arrival order
   for (int d0 = 0; d0 < D; d0 += TPP) {
     const int d = d0 + ck;
     float pg = 0.f, pb_ = 0.f;
@@ -684,12 +684,13 @@ __global__ __launch_bounds__(256) void ln_gate_bwd_kernel(const float* __restric
       pb_ += __shfl_xor(pb_, s);
     }
     if ((lane % PW) == 0 && d < D) {
-      atomicAdd(sred + d, pg);
-      atomicAdd(sred + D + d, pb_);
+      sred[wv * 2 * D + d] = pg;
+      sred[wv * 2 * D + D + d] = pb_;
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < 2 * D; i += blockDim.x) ws[(int64_t)blockIdx.x * 2 * D + i] = sred[i];   // one row per workgroup
+  for (int i = threadIdx.x; i < 2 * D; i += blockDim.x)       // one row per workgroup
+    ws[(int64_t)blockIdx.x * 2 * D + i] = (sred[i] + sred[2 * D + i]) + (sred[4 * D + i] + sred[6 * D + i]);
 }
 
 inline int pick_pw(int batch, int L) {   // positions per wave: fewer when there are few positions (small images)
@@ -784,9 +785,9 @@ __global__ __launch_bounds__(256) void ln_gate_bwd1_kernel(const float* __restri
   c2 = pos_sum<PW>(c2) / D;
   float* dmp = dm + (int64_t)b * dm_sb + p;
   float* dzp = dz + (int64_t)b * dz_sb + p;
-  extern __shared__ float sred[];                       // [2*D]: dgamma | dbeta of this workgroup (4 waves add into it)
-  for (int i = threadIdx.x; i < 2 * D; i += blockDim.x) sred[i] = 0.f;
-  __syncthreads();
+  extern __shared__ float sred[];                       // [4 waves][2*D]: dgamma | dbeta, one row per wave (plain stores: every
+                                                        // (wave, d) is written exactly once), summed in wave order below — no LDS
+                                                        // float atomics, so the result does not depend on the arrival order
 #pragma unroll
   for (int k = 0; k < CPL; ++k) {
     const int d = ck + k * TPP;
@@ -808,12 +809,13 @@ __global__ __launch_bounds__(256) void ln_gate_bwd1_kernel(const float* __restri
       pb_ += __shfl_xor(pb_, s_);
     }
     if ((lane % PW) == 0 && d < D) {
-      atomicAdd(sred + d, pg);
-      atomicAdd(sred + D + d, pb_);
+      sred[wv * 2 * D + d] = pg;
+      sred[wv * 2 * D + D + d] = pb_;
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < 2 * D; i += blockDim.x) ws[(int64_t)blockIdx.x * 2 * D + i] = sred[i];   // one row per workgroup
+  for (int i = threadIdx.x; i < 2 * D; i += blockDim.x)       // one row per workgroup
+    ws[(int64_t)blockIdx.x * 2 * D + i] = (sred[i] + sred[2 * D + i]) + (sred[4 * D + i] + sred[6 * D + i]);
 }
 
 // ---- cooperative single-pass variants for wide channel counts: the D channels of a position are split over ALL lanes of the
@@ -1083,7 +1085,7 @@ int launch_ln_bwd1(int cpl, dim3 grid, hipStream_t s, const float* dy, int64_t d
                    int64_t m_sd, const float* z, int64_t z_sb, int64_t z_sd, const float* gamma, const float* beta, const float* mu,
                    const float* rstd, float* dm, int64_t dm_sb, int64_t dm_sd, float* dz, int64_t dz_sb, int64_t dz_sd, float* ws,
                    int D, int L, int npb) {
-#define MM_LN_BWD1(CPL_) hipLaunchKernelGGL((ln_gate_bwd1_kernel<PW, CPL_>), grid, dim3(256), 2 * D * sizeof(float), s, dy, dy_sb, dy_sd, m, m_sb, m_sd, \
+#define MM_LN_BWD1(CPL_) hipLaunchKernelGGL((ln_gate_bwd1_kernel<PW, CPL_>), grid, dim3(256), 8 * D * sizeof(float), s, dy, dy_sb, dy_sd, m, m_sb, m_sd, \
                                             z, z_sb, z_sd, gamma, beta, mu, rstd, dm, dm_sb, dm_sd, dz, dz_sb, dz_sd, ws, D, L, npb)
   switch (cpl) {
     case 8: MM_LN_BWD1(8); break;
@@ -1209,9 +1211,9 @@ int mm_ln_gate_bwd(const float* dy, int64_t dy_sb, int64_t dy_sd, const float* m
     return pw == 16 ? launch_ln_bwd1<16>(pl.cpl, grid, s, dy, dy_sb, dy_sd, m, m_sb, m_sd, z, z_sb, z_sd, gamma, beta, mu, rstd, dm, dm_sb, dm_sd, dz, dz_sb, dz_sd, ws, D, L, npb)
                     : launch_ln_bwd1<4>(pl.cpl, grid, s, dy, dy_sb, dy_sd, m, m_sb, m_sd, z, z_sb, z_sd, gamma, beta, mu, rstd, dm, dm_sb, dm_sd, dz, dz_sb, dz_sd, ws, D, L, npb);
   }
-  if (pw == 64) hipLaunchKernelGGL(ln_gate_bwd_kernel<64>, grid, blk, 2 * D * sizeof(float), s, dy, dy_sb, dy_sd, m, m_sb, m_sd, z, z_sb, z_sd, gamma, beta, mu, rstd, dm, dm_sb, dm_sd, dz, dz_sb, dz_sd, ws, D, L, npb);
-  else if (pw == 16) hipLaunchKernelGGL(ln_gate_bwd_kernel<16>, grid, blk, 2 * D * sizeof(float), s, dy, dy_sb, dy_sd, m, m_sb, m_sd, z, z_sb, z_sd, gamma, beta, mu, rstd, dm, dm_sb, dm_sd, dz, dz_sb, dz_sd, ws, D, L, npb);
-  else hipLaunchKernelGGL(ln_gate_bwd_kernel<4>, grid, blk, 2 * D * sizeof(float), s, dy, dy_sb, dy_sd, m, m_sb, m_sd, z, z_sb, z_sd, gamma, beta, mu, rstd, dm, dm_sb, dm_sd, dz, dz_sb, dz_sd, ws, D, L, npb);
+  if (pw == 64) hipLaunchKernelGGL(ln_gate_bwd_kernel<64>, grid, blk, 8 * D * sizeof(float), s, dy, dy_sb, dy_sd, m, m_sb, m_sd, z, z_sb, z_sd, gamma, beta, mu, rstd, dm, dm_sb, dm_sd, dz, dz_sb, dz_sd, ws, D, L, npb);
+  else if (pw == 16) hipLaunchKernelGGL(ln_gate_bwd_kernel<16>, grid, blk, 8 * D * sizeof(float), s, dy, dy_sb, dy_sd, m, m_sb, m_sd, z, z_sb, z_sd, gamma, beta, mu, rstd, dm, dm_sb, dm_sd, dz, dz_sb, dz_sd, ws, D, L, npb);
+  else hipLaunchKernelGGL(ln_gate_bwd_kernel<4>, grid, blk, 8 * D * sizeof(float), s, dy, dy_sb, dy_sd, m, m_sb, m_sd, z, z_sb, z_sd, gamma, beta, mu, rstd, dm, dm_sb, dm_sd, dz, dz_sb, dz_sd, ws, D, L, npb);
   return (int)hipGetLastError();
 }
 
@@ -1323,9 +1325,8 @@ __global__ __launch_bounds__(256) void ln_half_bwd_kernel(const float* __restric
     }
   }
   // fold the RPW row slots of the wave (lanes with equal lr), then the 4 waves through LDS: one partial row per workgroup
-  extern __shared__ float sred[];                       // [2*C2]
-  for (int i = threadIdx.x; i < 2 * C2; i += blockDim.x) sred[i] = 0.f;
-  __syncthreads();
+  extern __shared__ float sred[];                       // [4 waves][2*C2]: one row per wave (plain stores), summed in wave order
+  const int wv = threadIdx.x >> 6;
 #pragma unroll
   for (int k = 0; k < kLnNV; ++k) {
     float a = ag[k], bsum = ab[k];
@@ -1334,10 +1335,11 @@ __global__ __launch_bounds__(256) void ln_half_bwd_kernel(const float* __restric
       bsum += __shfl_xor(bsum, 16); bsum += __shfl_xor(bsum, 32);
     }
     const int c = lr + k * TPR;
-    if (lane < TPR && c < C2) { atomicAdd(sred + c, a); atomicAdd(sred + C2 + c, bsum); }
+    if (lane < TPR && c < C2) { sred[wv * 2 * C2 + c] = a; sred[wv * 2 * C2 + C2 + c] = bsum; }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < 2 * C2; i += blockDim.x) ws[(int64_t)blockIdx.x * 2 * C2 + i] = sred[i];
+  for (int i = threadIdx.x; i < 2 * C2; i += blockDim.x)
+    ws[(int64_t)blockIdx.x * 2 * C2 + i] = (sred[i] + sred[2 * C2 + i]) + (sred[4 * C2 + i] + sred[6 * C2 + i]);
 }
 
 // dst[b, i, p] = src[b, p, i] for i < C2 (src row stride C): NHWC half -> NCHW.  REV: the other way round
@@ -1421,8 +1423,8 @@ int mm_block_split_bwd(const float* dleft_nchw, const float* drn, const float* d
   const int C = 2 * C2;
   const int64_t nrows = (int64_t)batch * P;
   hipLaunchKernelGGL(half_transpose_kernel<true>, dim3(((P + 31) / 32) * ((C2 + 31) / 32) * batch), dim3(256), 0, s, dleft_nchw, dinp, dres, P, C, C2);
-  if (C2 <= 128) hipLaunchKernelGGL(ln_half_bwd_kernel<16>, dim3(ln_half_grid(nrows, 16)), dim3(256), 2 * C2 * sizeof(float), s, drn, inp, gamma, mu, rstd, dres, dinp, ws, nrows, C, C2);
-  else hipLaunchKernelGGL(ln_half_bwd_kernel<64>, dim3(ln_half_grid(nrows, 64)), dim3(256), 2 * C2 * sizeof(float), s, drn, inp, gamma, mu, rstd, dres, dinp, ws, nrows, C, C2);
+  if (C2 <= 128) hipLaunchKernelGGL(ln_half_bwd_kernel<16>, dim3(ln_half_grid(nrows, 16)), dim3(256), 8 * C2 * sizeof(float), s, drn, inp, gamma, mu, rstd, dres, dinp, ws, nrows, C, C2);
+  else hipLaunchKernelGGL(ln_half_bwd_kernel<64>, dim3(ln_half_grid(nrows, 64)), dim3(256), 8 * C2 * sizeof(float), s, drn, inp, gamma, mu, rstd, dres, dinp, ws, nrows, C, C2);
   return (int)hipGetLastError();
 }
 
@@ -1581,14 +1583,14 @@ __global__ __launch_bounds__(512) void channel_sum_nchw_kernel(const float* __re
   if (threadIdx.x == 0) {
     float t = 0.f;
     for (int j = 0; j < (int)(blockDim.x >> 6); ++j) t += red[j];
-    if constexpr (ATOMIC) atomicAdd(out + c, t); else out[c] = t;
+    if constexpr (ATOMIC) out[(int64_t)part * C + c] = t; else out[c] = t;     // (ATOMIC = several batch parts: one row per part, no atomics)
   }
 }
 }  // namespace
 
 extern "C" {
 
-int mm_channel_sum_nchw_split(int batch, int C) {      // > 1: the caller must zero-fill `out` (atomics)
+int mm_channel_sum_nchw_split(int batch, int C) {      // > 1: `out` holds that many rows of C partial sums (the caller adds them)
   int s = 1;
   while (C * s < 256 && s * 2 <= batch && s < 16) s *= 2;
   return s;

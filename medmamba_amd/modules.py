@@ -487,7 +487,8 @@ class SS_Conv_SSM(nn.Module):
             body = _ConvBody(mods)
             bufs = [(b, b.detach().clone()) for b in body.buffers()]
             sample = torch.randn_like(left).requires_grad_()
-            g = torch.cuda.make_graphed_callables(body, (sample,))
+            with ops.immediate_bn_counters():
+                g = torch.cuda.make_graphed_callables(body, (sample,))
             with torch.no_grad():
                 for b, saved in bufs:
                     b.copy_(saved)
@@ -609,7 +610,8 @@ class VSSLayer(nn.Module):
             bufs = [(b, b.detach().clone()) for b in blk.buffers()]
             sx = torch.randn_like(x).requires_grad_()
             sf = torch.ones(x.shape[0], device=x.device, dtype=torch.float32)
-            g = torch.cuda.make_graphed_callables(wrap, (sx, sf))
+            with ops.immediate_bn_counters():
+                g = torch.cuda.make_graphed_callables(wrap, (sx, sf))
             with torch.no_grad():
                 for b, saved in bufs:
                     b.copy_(saved)

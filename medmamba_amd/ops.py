@@ -487,11 +487,12 @@ def channel_sum_nchw(x):
     B, C = x.shape[0], x.shape[1]
     HW = x.numel() // (B * C)
     lib = _lib.lib()
-    out = (torch.zeros if lib.mm_channel_sum_nchw_split(B, C) > 1 else torch.empty)((C,), device=x.device, dtype=torch.float32)
+    split = lib.mm_channel_sum_nchw_split(B, C)
+    out = torch.empty((split, C), device=x.device, dtype=torch.float32)
     with _lib.device_guard(x.device):
         rc = lib.mm_channel_sum_nchw(x.data_ptr(), out.data_ptr(), B, C, HW, _stream())
     _lib.check(rc, "mm_channel_sum_nchw")
-    return out
+    return out[0] if split == 1 else out.sum(0)        # rows of per-batch-part sums, added in a fixed order (no atomics)
 
 
 def _bias_grad(dy):
@@ -826,7 +827,8 @@ _DEFERRED_COUNTERS = None      # list while a caller batches the BatchNorm step 
 class deferred_bn_counters:
     """Inside this context the `num_batches_tracked += 1` of every BatchNorm that bn_relu_train runs is collected and applied
     by ONE multi-tensor add on exit (42 one-element launches per MedMamba-S step otherwise).  Only for the default
-    momentum semantics; a BatchNorm with momentum=None needs its counter at once and keeps the immediate add."""
+    momentum semantics; a BatchNorm with momentum=None needs its counter at once and keeps the immediate add, and so does a
+    forward that is being captured into a hipGraph (the add must be part of what is replayed)."""
 
     def __enter__(self):
         global _DEFERRED_COUNTERS
@@ -841,11 +843,26 @@ class deferred_bn_counters:
         return False
 
 
+class immediate_bn_counters:
+    """Suspends deferred_bn_counters: for code that snapshots / restores BatchNorm buffers around forward passes (the warm-up and
+    capture passes of a hipGraph build) and needs every counter update to have happened when the pass returns."""
+
+    def __enter__(self):
+        global _DEFERRED_COUNTERS
+        self.prev, _DEFERRED_COUNTERS = _DEFERRED_COUNTERS, None
+        return self
+
+    def __exit__(self, *exc):
+        global _DEFERRED_COUNTERS
+        _DEFERRED_COUNTERS = self.prev
+        return False
+
+
 def bn_relu_train(x, bn, relu, partials=None):
     """`bn` (an nn.BatchNorm2d in training mode, affine, default momentum semantics) applied to x, optionally followed by
     ReLU, through BNReluFn; num_batches_tracked advances as in the module's own forward."""
     if bn.track_running_stats and bn.num_batches_tracked is not None:
-        if _DEFERRED_COUNTERS is not None and bn.momentum is not None:
+        if _DEFERRED_COUNTERS is not None and bn.momentum is not None and not torch.cuda.is_current_stream_capturing():
             _DEFERRED_COUNTERS.append(bn.num_batches_tracked)
         else:
             bn.num_batches_tracked.add_(1)
