@@ -168,17 +168,20 @@ int mm_scan_dt_max(void);
  * channel-first (batch, C2, P) like left; inp, out: block input / output NHWC (batch, P, 2*C2); contiguous fp32, P = H*W.
  * Two neighbours of the chain are folded in (both optional):
  *   left_relu != 0 : `left` is the PRE-activation of the conv branch's trailing nn.ReLU (MedMamba.py:347), applied here;
- *   ssm_scale (batch) or NULL: per-sample DropPath factor mask/keep_prob of self.drop_path (MedMamba.py:335, 353).
+ *   ssm_scale (batch) or NULL: per-sample DropPath factor mask/keep_prob of self.drop_path (MedMamba.py:335, 353);
+ *   left_bias (C2) or NULL: the bias of the conv branch's closing 1x1 convolution (MedMamba.py:345), added to `left` before the
+ *   ReLU here instead of by a pass of its own (the 1x1 convolution is a bias-free GEMM then); the backward needs the same
+ *   pointer for the ReLU mask (left_pre + left_bias > 0).
  * Backward: dleft (batch, C2, P) and dssm (same layout as ssm) from dout (batch, P, 2*C2); d(inp) = dout;
  *   left_pre = the same pre-activation (ReLU mask) or NULL.
  * ssm_sb / ssm_sd (dssm_*): batch / channel element strides of a channel-first ssm (plane (b,i) at ssm + b*sb + i*sd,
  *   unit stride along P); both 0 = contiguous (batch, C2, P).  Ignored for the NHWC form. */
 int mm_shuffle_residual_fwd(const float* left, const float* ssm, int64_t ssm_sb, int64_t ssm_sd, const float* inp, float* out,
-                            const float* ssm_scale, int left_relu, int batch, int P, int C2, int ssm_channel_first,
-                            void* stream);
+                            const float* ssm_scale, int left_relu, const float* left_bias, int batch, int P, int C2,
+                            int ssm_channel_first, void* stream);
 int mm_shuffle_residual_bwd(const float* dout, float* dleft, float* dssm, int64_t dssm_sb, int64_t dssm_sd,
-                            const float* ssm_scale, const float* left_pre, int batch, int P, int C2, int ssm_channel_first,
-                            void* stream);
+                            const float* ssm_scale, const float* left_pre, const float* left_bias, int batch, int P, int C2,
+                            int ssm_channel_first, void* stream);
 
 /* ---- SS2D in channel-first planes (everything between in_proj and out_proj is (batch, channel, H*W)) ----------
  * Plane tensors are addressed as base + b*X_sb + d*X_sd (element strides, unit stride along H*W), so the same kernels
@@ -271,10 +274,15 @@ int mm_nchw_ln_rows_bwd(const float* dy, const float* x, const float* gamma, con
  * statistics (biased variance) for the normalisation; running_mean / running_var (either may be NULL) updated in place with
  * `momentum` and the unbiased variance.  mean / rstd (C): saved batch statistics for the backward.
  * ws: scratch of 3 * C * mm_bn_splits(batch, C, HW) floats (partial statistics; need not be initialised).
- * relu != 0: y = max(0, bn(x)); the backward masks dy where bn(x) <= 0 (recomputed from x, y is not needed). */
+ * relu != 0: y = max(0, bn(x)); the backward masks dy where bn(x) <= 0 (recomputed from x, y is not needed).
+ * pre_bias (C) or NULL: x is a convolution's output WITHOUT its per-channel bias (MedMamba.py:339-340, 342-343: conv -> BatchNorm).
+ *   BatchNorm(x + bias) and BatchNorm(x) normalise to the same values (the batch mean absorbs the constant); only the running mean
+ *   differs, and it is updated with mean(x) + pre_bias — so the bias add over the conv output never has to run.  mean / rstd
+ *   returned are those of x (what the backward, which is also given x, needs). */
 int mm_bn_splits(int batch, int C, int HW);
 int mm_bn_relu_fwd(const float* x, const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
-                   float* running_var, float* y, float* mean, float* rstd, float* ws, int relu, int batch, int C, int HW, void* stream);
+                   float* running_var, float* y, float* mean, float* rstd, float* ws, const float* pre_bias, int relu, int batch, int C,
+                   int HW, void* stream);
 /* The same forward with the batch statistics already available as `nparts` partials per channel, partials[(q*C + c)*3 + (0: count,
  * 1: mean, 2: M2 = sum of squared deviations from that mean)] — what mm_conv3x3_fwd emits for its output: one pass (apply) only. */
 int mm_bn_relu_fwd_stats(const float* x, const float* partials, int nparts, const float* gamma, const float* beta, float eps,

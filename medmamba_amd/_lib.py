@@ -54,7 +54,7 @@ SYMBOLS = {
     "mm_scan_fwd": (ctypes.c_int, [ctypes.POINTER(ScanArgs), ctypes.c_void_p]),
     "mm_scan_bwd": (ctypes.c_int, [ctypes.POINTER(ScanArgs), ctypes.c_void_p]),
     "mm_scan_plan": (ctypes.c_int, [ctypes.POINTER(ScanArgs), ctypes.c_int, ctypes.POINTER(ctypes.c_int32)]),
-    "mm_shuffle_residual_fwd": (ctypes.c_int, [_f32p, _f32p, _i64, _i64, _f32p, _f32p, _f32p] + [ctypes.c_int] * 5 + [ctypes.c_void_p]),
+    "mm_shuffle_residual_fwd": (ctypes.c_int, [_f32p, _f32p, _i64, _i64, _f32p, _f32p, _f32p, ctypes.c_int, _f32p] + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
     "mm_dwconv_silu_cross_fwd": (ctypes.c_int, [_f32p, _i64, _i64, _f32p, _f32p, _f32p, _i64, _i64] + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
     "mm_dwconv_silu_cross_supported": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
     "mm_dwconv_silu_cross_strips": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
@@ -71,7 +71,7 @@ SYMBOLS = {
                            + [ctypes.c_void_p]),
     "mm_block_split_bwd": (ctypes.c_int, [_f32p] * 9 + [ctypes.c_int] * 3 + [ctypes.c_void_p]),
     "mm_block_split_rows": (ctypes.c_int, [ctypes.c_int] * 3),
-    "mm_shuffle_residual_bwd": (ctypes.c_int, [_f32p, _f32p, _f32p, _i64, _i64, _f32p, _f32p] + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
+    "mm_shuffle_residual_bwd": (ctypes.c_int, [_f32p, _f32p, _f32p, _i64, _i64, _f32p, _f32p, _f32p] + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
     "mm_patch_merge_ln_supported": (ctypes.c_int, [ctypes.c_int]),
     "mm_patch_merge_ln_rows": (ctypes.c_int, [ctypes.c_int] * 3),
     "mm_patch_merge_ln_fwd": (ctypes.c_int, [_f32p, _f32p, _f32p, ctypes.c_float, _f32p, _f32p, _f32p] + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
@@ -81,7 +81,7 @@ SYMBOLS = {
     "mm_nchw_ln_rows_fwd": (ctypes.c_int, [_f32p, _f32p, _f32p, ctypes.c_float, _f32p, _f32p, _f32p] + [ctypes.c_int] * 3 + [ctypes.c_void_p]),
     "mm_nchw_ln_rows_bwd": (ctypes.c_int, [_f32p] * 7 + [ctypes.c_int] * 3 + [ctypes.c_void_p]),
     "mm_bn_splits": (ctypes.c_int, [ctypes.c_int] * 3),
-    "mm_bn_relu_fwd": (ctypes.c_int, [_f32p, _f32p, _f32p, ctypes.c_float, ctypes.c_float, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p]
+    "mm_bn_relu_fwd": (ctypes.c_int, [_f32p, _f32p, _f32p, ctypes.c_float, ctypes.c_float, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p]
                        + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
     "mm_bn_relu_fwd_stats": (ctypes.c_int, [_f32p, _f32p, ctypes.c_int, _f32p, _f32p, ctypes.c_float, ctypes.c_float, _f32p, _f32p, _f32p, _f32p,
                                             _f32p] + [ctypes.c_int] * 4 + [ctypes.c_void_p]),

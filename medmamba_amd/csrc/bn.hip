@@ -88,7 +88,8 @@ __global__ __launch_bounds__(256) void bn_apply_fwd_kernel(const float* __restri
                                                            const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                                            float momentum, float* __restrict__ running_mean,
                                                            float* __restrict__ running_var, float* __restrict__ y,
-                                                           float* __restrict__ mean_out, float* __restrict__ rstd_out, int relu, BnGeom g) {
+                                                           float* __restrict__ mean_out, float* __restrict__ rstd_out, int relu,
+                                                           const float* __restrict__ pre_bias, BnGeom g) {
   const int c = blockIdx.x % g.C, s = blockIdx.x / g.C;
   float n, mean, m2;
   bn_merge(partial, c, g, n, mean, m2);
@@ -97,7 +98,9 @@ __global__ __launch_bounds__(256) void bn_apply_fwd_kernel(const float* __restri
   const float sc = rstd * gamma[c], sh = beta[c] - mean * sc;
   if (s == 0 && threadIdx.x == 0) {
     mean_out[c] = mean; rstd_out[c] = rstd;
-    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+    // pre_bias: x is the output of a convolution WITHOUT its bias; BatchNorm(x + bias) == BatchNorm(x) except for the running
+    // mean, which follows the biased tensor (the separate bias-add pass over x never runs)
+    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (mean + (pre_bias ? pre_bias[c] : 0.f));
     if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (n > 1.f ? m2 / (n - 1.f) : var);
   }
   const int b0 = s * g.nb, b1 = min(b0 + g.nb, g.batch);
@@ -216,7 +219,8 @@ extern "C" {
 int mm_bn_splits(int batch, int C, int HW) { return (batch > 0 && C > 0 && HW > 0) ? bn_geom(batch, C, HW).S : 0; }
 
 int mm_bn_relu_fwd(const float* x, const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
-                   float* running_var, float* y, float* mean, float* rstd, float* ws, int relu, int batch, int C, int HW, void* stream) {
+                   float* running_var, float* y, float* mean, float* rstd, float* ws, const float* pre_bias, int relu, int batch, int C,
+                   int HW, void* stream) {
   if (!x || !gamma || !beta || !y || !mean || !rstd || !ws) return MM_ERR_NULL;
   if (batch <= 0 || C <= 0 || HW <= 0) return MM_ERR_SHAPE;
   if ((int64_t)batch * HW < 2) return MM_ERR_SHAPE;          // (torch raises for a single value per channel as well)
@@ -224,7 +228,7 @@ int mm_bn_relu_fwd(const float* x, const float* gamma, const float* beta, float 
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(bn_stats_kernel, dim3(C * g.S), dim3(256), 0, s, x, ws, g);
   hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3(C * g.S), dim3(256), 0, s, x, ws, gamma, beta, eps, momentum, running_mean, running_var, y, mean,
-                     rstd, relu, g);
+                     rstd, relu, pre_bias, g);
   return (int)hipGetLastError();
 }
 
@@ -237,7 +241,7 @@ int mm_bn_relu_fwd_stats(const float* x, const float* partials, int nparts, cons
   BnGeom g = bn_geom(batch, C, HW);
   g.SP = nparts;
   hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3(C * g.S), dim3(256), 0, (hipStream_t)stream, x, partials, gamma, beta, eps, momentum,
-                     running_mean, running_var, y, mean, rstd, relu, g);
+                     running_mean, running_var, y, mean, rstd, relu, (const float*)nullptr, g);
   return (int)hipGetLastError();
 }
 

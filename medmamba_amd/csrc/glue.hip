@@ -19,6 +19,7 @@ template <bool SSM_CF>
 __global__ __launch_bounds__(256) void shuffle_residual_fwd_kernel(const float* __restrict__ left, const float* __restrict__ ssm,
                                                                    const float* __restrict__ inp, float* __restrict__ out,
                                                                    const float* __restrict__ ssm_scale, int left_relu,
+                                                                   const float* __restrict__ left_bias,
                                                                    int64_t ssm_sb, int64_t ssm_sd, int P, int C2) {
   __shared__ float tile[32][33];
   __shared__ float tile2[SSM_CF ? 32 : 1][33];
@@ -31,7 +32,7 @@ __global__ __launch_bounds__(256) void shuffle_residual_fwd_kernel(const float* 
 #pragma unroll
   for (int r = ty; r < 32; r += 8) {
     const int i = i0 + r, p = p0 + tx;
-    tile[r][tx] = (i < C2 && p < P) ? lb[(int64_t)i * P + p] : 0.f;
+    tile[r][tx] = (i < C2 && p < P) ? lb[(int64_t)i * P + p] + (left_bias ? left_bias[i] : 0.f) : 0.f;
     if constexpr (SSM_CF) tile2[r][tx] = (i < C2 && p < P) ? ssm[b * ssm_sb + i * ssm_sd + p] : 0.f;
   }
   __syncthreads();
@@ -52,7 +53,8 @@ __global__ __launch_bounds__(256) void shuffle_residual_fwd_kernel(const float* 
 template <bool SSM_CF>
 __global__ __launch_bounds__(256) void shuffle_residual_bwd_kernel(const float* __restrict__ dout, float* __restrict__ dleft,
                                                                    float* __restrict__ dssm, const float* __restrict__ ssm_scale,
-                                                                   const float* __restrict__ left_pre, int64_t dssm_sb,
+                                                                   const float* __restrict__ left_pre,
+                                                                   const float* __restrict__ left_bias, int64_t dssm_sb,
                                                                    int64_t dssm_sd, int P, int C2) {
   __shared__ float tile[32][33];
   __shared__ float tile2[SSM_CF ? 32 : 1][33];
@@ -79,7 +81,7 @@ __global__ __launch_bounds__(256) void shuffle_residual_bwd_kernel(const float* 
   for (int r = ty; r < 32; r += 8) {
     const int i = i0 + r, p = p0 + tx;
     if (i < C2 && p < P) {
-      const bool on = lp ? lp[(int64_t)i * P + p] > 0.0f : true;
+      const bool on = lp ? lp[(int64_t)i * P + p] + (left_bias ? left_bias[i] : 0.f) > 0.0f : true;
       lb[(int64_t)i * P + p] = on ? tile[tx][r] : 0.0f;
       if constexpr (SSM_CF) dssm[b * dssm_sb + i * dssm_sd + p] = tile2[tx][r];
     }
@@ -90,28 +92,28 @@ __global__ __launch_bounds__(256) void shuffle_residual_bwd_kernel(const float* 
 extern "C" {
 
 int mm_shuffle_residual_fwd(const float* left, const float* ssm, int64_t ssm_sb, int64_t ssm_sd, const float* inp, float* out,
-                            const float* ssm_scale, int left_relu, int batch, int P, int C2, int ssm_channel_first,
-                            void* stream) {
+                            const float* ssm_scale, int left_relu, const float* left_bias, int batch, int P, int C2,
+                            int ssm_channel_first, void* stream) {
   if (ssm_sb == 0 && ssm_sd == 0) { ssm_sb = (int64_t)C2 * P; ssm_sd = P; }
   if (!left || !ssm || !inp || !out) return MM_ERR_NULL;
   if (batch <= 0 || P <= 0 || C2 <= 0 || batch > 65535) return MM_ERR_SHAPE;
   if ((reinterpret_cast<uintptr_t>(inp) | reinterpret_cast<uintptr_t>(out)) & 7) return MM_ERR_ALIGN;
   dim3 grid((P + 31) / 32, (C2 + 31) / 32, batch);
-  if (ssm_channel_first) hipLaunchKernelGGL(shuffle_residual_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, left, ssm, inp, out, ssm_scale, left_relu, ssm_sb, ssm_sd, P, C2);
-  else hipLaunchKernelGGL(shuffle_residual_fwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, left, ssm, inp, out, ssm_scale, left_relu, ssm_sb, ssm_sd, P, C2);
+  if (ssm_channel_first) hipLaunchKernelGGL(shuffle_residual_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, left, ssm, inp, out, ssm_scale, left_relu, left_bias, ssm_sb, ssm_sd, P, C2);
+  else hipLaunchKernelGGL(shuffle_residual_fwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, left, ssm, inp, out, ssm_scale, left_relu, left_bias, ssm_sb, ssm_sd, P, C2);
   return (int)hipGetLastError();
 }
 
 int mm_shuffle_residual_bwd(const float* dout, float* dleft, float* dssm, int64_t dssm_sb, int64_t dssm_sd,
-                            const float* ssm_scale, const float* left_pre, int batch, int P, int C2, int ssm_channel_first,
-                            void* stream) {
+                            const float* ssm_scale, const float* left_pre, const float* left_bias, int batch, int P, int C2,
+                            int ssm_channel_first, void* stream) {
   if (dssm_sb == 0 && dssm_sd == 0) { dssm_sb = (int64_t)C2 * P; dssm_sd = P; }
   if (!dout || !dleft || !dssm) return MM_ERR_NULL;
   if (batch <= 0 || P <= 0 || C2 <= 0 || batch > 65535) return MM_ERR_SHAPE;
   if (reinterpret_cast<uintptr_t>(dout) & 7) return MM_ERR_ALIGN;
   dim3 grid((P + 31) / 32, (C2 + 31) / 32, batch);
-  if (ssm_channel_first) hipLaunchKernelGGL(shuffle_residual_bwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, dout, dleft, dssm, ssm_scale, left_pre, dssm_sb, dssm_sd, P, C2);
-  else hipLaunchKernelGGL(shuffle_residual_bwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, dout, dleft, dssm, ssm_scale, left_pre, dssm_sb, dssm_sd, P, C2);
+  if (ssm_channel_first) hipLaunchKernelGGL(shuffle_residual_bwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, dout, dleft, dssm, ssm_scale, left_pre, left_bias, dssm_sb, dssm_sd, P, C2);
+  else hipLaunchKernelGGL(shuffle_residual_bwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, dout, dleft, dssm, ssm_scale, left_pre, left_bias, dssm_sb, dssm_sd, P, C2);
   return (int)hipGetLastError();
 }
 

@@ -65,9 +65,10 @@ def _is_pointwise(m):
             and m.dilation == (1, 1) and m.groups == 1 and m.padding_mode == "zeros")
 
 
-def _conv_branch(mods, x):
+def _conv_branch(mods, x, skip_last_bias=False):
     """Run the modules of the conv branch in order; dense convs with a bias go through ops.conv2d_bias (same MIOpen
-    kernels, fast bias gradient), 1x1 convs through PointwiseConvFn (batched GEMM)."""
+    kernels, fast bias gradient), 1x1 convs through PointwiseConvFn (batched GEMM).
+    skip_last_bias: the last module is a 1x1 conv whose bias the caller applies itself (shuffle_residual's left_bias)."""
     mods = list(mods)
     i = 0
     while i < len(mods):
@@ -76,7 +77,7 @@ def _conv_branch(mods, x):
                                 and t.dim() == 4 and (bn.training or not bn.track_running_stats))
         if isinstance(m, nn.Conv2d) and x.is_cuda:
             if _is_pointwise(m):
-                x = PointwiseConvFn.apply(x, m.weight, m.bias)
+                x = PointwiseConvFn.apply(x, m.weight, None if (skip_last_bias and i == len(mods) - 1) else m.bias)
             elif ops.own_conv3x3_ok(x, m):
                 # our MFMA conv: bias in its epilogue, and — when one of our BatchNorms follows — that BatchNorm's statistics
                 # pass too (the BatchNorm then only applies)
@@ -89,7 +90,16 @@ def _conv_branch(mods, x):
                 else:
                     x = ops.Conv3x3Fn.apply(x, m.weight, m.bias, False)
             else:
-                x = conv2d_bias(x, m)
+                nxt = mods[i + 1] if i + 1 < len(mods) else None
+                if nxt is not None and own_bn(nxt, x) and nxt.track_running_stats and ops.conv2d_bias_ok(x, m):
+                    # conv -> BatchNorm (MedMamba.py:339-340, 342-343): the conv's bias changes nothing but the BatchNorm's running
+                    # mean — the conv runs without it and the BatchNorm kernel accounts for it (no bias-add pass)
+                    x = conv2d_bias(x, m, add_bias=False)
+                    relu = i + 2 < len(mods) and type(mods[i + 2]) is nn.ReLU
+                    x = bn_relu_train(x, nxt, relu, pre_bias=m.bias)
+                    i += 2 if relu else 1
+                else:
+                    x = conv2d_bias(x, m)
         elif own_bn(m, x):
             # training-mode BatchNorm through our kernels; a directly following nn.ReLU is folded into them
             relu = i + 1 < len(mods) and type(mods[i + 1]) is nn.ReLU
@@ -460,7 +470,8 @@ class SS_Conv_SSM(nn.Module):
         def conv_body(t):
             t = self._conv_relu(t, *fold["a"], fold["pad_a"])
             t = self._conv_relu(t, *fold["b"], fold["pad_b"])
-            return PointwiseConvFn.apply(t, conv[7].weight, conv[7].bias)         # pre-activation of the trailing ReLU
+            return PointwiseConvFn.apply(t, conv[7].weight, None)                 # pre-activation of the trailing ReLU, without
+                                                                                  # the bias (shuffle_residual adds it)
 
         if _TWO_STREAMS:
             main = torch.cuda.current_stream()
@@ -475,7 +486,7 @@ class SS_Conv_SSM(nn.Module):
         else:
             x_cf = self.self_attention.forward_cf(right_n)
             left = conv_body(left)
-        return shuffle_residual(left, x_cf, input, channel_first=True, ssm_scale=None, left_relu=True)
+        return shuffle_residual(left, x_cf, input, channel_first=True, ssm_scale=None, left_relu=True, left_bias=conv[7].bias)
 
     def _graphed_conv_body(self, mods, left):
         """torch.cuda.make_graphed_callables over the conv branch for this input shape (built once per shape).  The BatchNorm
@@ -524,8 +535,14 @@ class SS_Conv_SSM(nn.Module):
         conv = self.conv33conv33conv11
         fold_relu = isinstance(conv[-1], nn.ReLU)              # the trailing ReLU (:347) is applied by shuffle_residual
         mods = list(conv)[:-1] if fold_relu else list(conv)
-        conv_body = lambda t: _conv_branch(mods, t)
-        if _GRAPH_CONV and self.training and torch.is_grad_enabled() and input.is_cuda:
+        graph_conv = _GRAPH_CONV and self.training and torch.is_grad_enabled() and input.is_cuda
+        # the closing 1x1 conv's bias (MedMamba.py:345) is added by shuffle_residual in front of the ReLU it applies anyway: the
+        # conv is a bias-free GEMM (a broadcast bias costs baddbmm a fill pass over the whole output first)
+        last = mods[-1] if mods else None
+        defer_bias = (fold_relu and not graph_conv and input.is_cuda and last is not None and _is_pointwise(last)
+                      and last.bias is not None)
+        conv_body = lambda t: _conv_branch(mods, t, skip_last_bias=defer_bias)
+        if graph_conv:
             conv_body = self._graphed_conv_body(mods, left)
         if _TWO_STREAMS and input.is_cuda:
             # the conv branch and the SS2D branch are independent (MedMamba.py:351-353): run the conv branch on a side
@@ -558,7 +575,8 @@ class SS_Conv_SSM(nn.Module):
         scale = getattr(self, "_dp_factor", None)      # drawn for all blocks at once by VSSM.forward_backbone
         if scale is None:
             scale = self.drop_path.factor(x_cf)
-        return shuffle_residual(left, x_cf, input, channel_first=True, ssm_scale=scale, left_relu=fold_relu)
+        return shuffle_residual(left, x_cf, input, channel_first=True, ssm_scale=scale, left_relu=fold_relu,
+                                left_bias=last.bias if defer_bias else None)
 
 
 class _GraphableBlock(nn.Module):

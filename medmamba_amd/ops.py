@@ -85,8 +85,9 @@ class ShuffleResidualFn(torch.autograd.Function):
     the DropPath factor mask / keep_prob of every sample (MedMamba.py:335, 353)."""
 
     @staticmethod
-    def forward(ctx, left, ssm, inp, channel_first, ssm_scale, left_relu):
+    def forward(ctx, left, ssm, inp, channel_first, ssm_scale, left_relu, left_bias=None):
         left, inp = left.float().contiguous(), inp.float().contiguous()
+        left_bias = None if left_bias is None else left_bias.float().contiguous()
         ssm = _rows(ssm) if channel_first else ssm.float().contiguous()
         B, C2, H, W = left.shape
         if ssm_scale is not None:
@@ -97,18 +98,19 @@ class ShuffleResidualFn(torch.autograd.Function):
         with _lib.device_guard(inp.device):
             rc = _lib.lib().mm_shuffle_residual_fwd(left.data_ptr(), ssm.data_ptr(), sb, sd, inp.data_ptr(), out.data_ptr(),
                                                     None if ssm_scale is None else ssm_scale.data_ptr(), int(bool(left_relu)),
+                                                    None if left_bias is None else left_bias.data_ptr(),
                                                     B, H * W, C2, int(channel_first), _stream())
         _lib.check(rc, "mm_shuffle_residual_fwd")
         ctx.shape = (B, C2, H, W)
         ctx.cf = bool(channel_first)
         ctx.cm = bool(channel_first) and _is_cm(ssm) and B > 1
-        ctx.save_for_backward(ssm_scale, left if left_relu else None)
+        ctx.save_for_backward(ssm_scale, left if left_relu else None, left_bias)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         B, C2, H, W = ctx.shape
-        ssm_scale, left_pre = ctx.saved_tensors
+        ssm_scale, left_pre, left_bias = ctx.saved_tensors
         dout = dout.float().contiguous()
         dleft = torch.empty((B, C2, H, W), device=dout.device, dtype=torch.float32)
         if ctx.cf:
@@ -121,14 +123,17 @@ class ShuffleResidualFn(torch.autograd.Function):
             rc = _lib.lib().mm_shuffle_residual_bwd(dout.data_ptr(), dleft.data_ptr(), dssm.data_ptr(), sb, sd,
                                                     None if ssm_scale is None else ssm_scale.data_ptr(),
                                                     None if left_pre is None else left_pre.data_ptr(),
+                                                    None if (left_bias is None or left_pre is None) else left_bias.data_ptr(),
                                                     B, H * W, C2, int(ctx.cf), _stream())
         _lib.check(rc, "mm_shuffle_residual_bwd")
-        return dleft, dssm, dout, None, None, None
+        # d(left_bias) = channel sums of dleft (the bias sits in front of the ReLU whose mask dleft already carries)
+        dlb = _bias_grad(dleft) if (left_bias is not None and ctx.needs_input_grad[6]) else None
+        return dleft, dssm, dout, None, None, None, dlb
 
 
-def shuffle_residual(left_nchw, ssm, inp_nhwc, channel_first=False, ssm_scale=None, left_relu=False):
+def shuffle_residual(left_nchw, ssm, inp_nhwc, channel_first=False, ssm_scale=None, left_relu=False, left_bias=None):
     _need_hip(left_nchw, ssm, inp_nhwc)
-    return ShuffleResidualFn.apply(left_nchw, ssm, inp_nhwc, channel_first, ssm_scale, left_relu)
+    return ShuffleResidualFn.apply(left_nchw, ssm, inp_nhwc, channel_first, ssm_scale, left_relu, left_bias)
 
 
 class InProjFn(torch.autograd.Function):
@@ -404,7 +409,7 @@ class SS2DCoreFn(torch.autograd.Function):
         if cm:
             dd = ddelta.permute(1, 0, 2).reshape(4, D, Q)                                      # views of (4D, B, L) storage
             torch.bmm(dd, x_dbl[:, :R].transpose(1, 2), out=dWdt)                               # (4, D, R)
-            dx_dbl[:, :R] = torch.bmm(Wdt.transpose(1, 2), dd)                                  # dt rows of d(x_dbl)
+            torch.bmm(Wdt.transpose(1, 2), dd, out=dx_dbl[:, :R])                               # dt rows of d(x_dbl), in place
             dx2 = dx_dbl.view(2, 2 * C, Q)
             if fused_conv:
                 du2m = torch.bmm(Wx.view(2, 2 * C, D).transpose(1, 2), dx2)                      # Wx^T d(x_dbl); pairs added later
@@ -507,8 +512,11 @@ class ConvBiasFn(torch.autograd.Function):
     generic reduction takes 59 us for a 64x48x56x56 gradient (0.65 TB/s), mm_channel_sum_nchw a fraction of that."""
 
     @staticmethod
-    def forward(ctx, x, w, b, stride, padding, dilation):
-        y = torch.nn.functional.conv2d(x, w, b, stride, padding, dilation)
+    def forward(ctx, x, w, b, stride, padding, dilation, add_bias=True):
+        # add_bias=False: the caller folds the bias into the BatchNorm that follows (ops.bn_relu_train(pre_bias=...)): y is the
+        # convolution WITHOUT bias (MIOpen adds a bias in a separate elementwise pass: 47 us at 64 x 48 x 56 x 56); the bias
+        # still gets its gradient (the channel sums of dy) below
+        y = torch.nn.functional.conv2d(x, w, b if add_bias else None, stride, padding, dilation)
         ctx.save_for_backward(x, w)
         ctx.cfg = (list(stride), list(padding), list(dilation), b is not None)
         return y
@@ -521,14 +529,20 @@ class ConvBiasFn(torch.autograd.Function):
         dx, dw, _ = torch.ops.aten.convolution_backward(dy, x, w, None, stride, padding, dilation, False, [0, 0], 1,
                                                         [ctx.needs_input_grad[0], ctx.needs_input_grad[1], False])
         db = _bias_grad(dy) if (has_bias and ctx.needs_input_grad[2]) else None
-        return dx, dw, db, None, None, None
+        return dx, dw, db, None, None, None, None
 
 
-def conv2d_bias(x, conv):
-    """nn.Conv2d `conv` applied to x with ConvBiasFn when it is a plain dense conv with a bias on a HIP tensor."""
-    if (x.is_cuda and conv.bias is not None and conv.groups == 1 and conv.padding_mode == "zeros"
-            and not isinstance(conv.padding, str) and x.dtype == torch.float32 and x.is_contiguous()):
-        return ConvBiasFn.apply(x, conv.weight, conv.bias, conv.stride, conv.padding, conv.dilation)
+def conv2d_bias_ok(x, conv):
+    return (x.is_cuda and conv.bias is not None and conv.groups == 1 and conv.padding_mode == "zeros"
+            and not isinstance(conv.padding, str) and x.dtype == torch.float32 and x.is_contiguous())
+
+
+def conv2d_bias(x, conv, add_bias=True):
+    """nn.Conv2d `conv` applied to x with ConvBiasFn when it is a plain dense conv with a bias on a HIP tensor.
+    add_bias=False (only when conv2d_bias_ok): the output lacks the bias, see ConvBiasFn."""
+    if conv2d_bias_ok(x, conv):
+        return ConvBiasFn.apply(x, conv.weight, conv.bias, conv.stride, conv.padding, conv.dilation, add_bias)
+    assert add_bias
     return conv(x)
 
 
@@ -773,7 +787,7 @@ class BNReluFn(torch.autograd.Function):
     caller advances num_batches_tracked."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, relu, partials=None):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, relu, partials=None, pre_bias=None):
         x = x.float().contiguous()
         gamma, beta = gamma.float().contiguous(), beta.float().contiguous()
         B, C = x.shape[0], x.shape[1]
@@ -795,8 +809,8 @@ class BNReluFn(torch.autograd.Function):
             ws = torch.empty((3 * C * lib.mm_bn_splits(B, C, HW),), device=dev, dtype=torch.float32)
             with _lib.device_guard(dev):
                 rc = lib.mm_bn_relu_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), float(eps), float(momentum), rm, rv,
-                                        y.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), ws.data_ptr(), int(bool(relu)),
-                                        B, C, HW, _stream())
+                                        y.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), ws.data_ptr(),
+                                        None if pre_bias is None else pre_bias.data_ptr(), int(bool(relu)), B, C, HW, _stream())
             _lib.check(rc, "mm_bn_relu_fwd")
         ctx.save_for_backward(x, gamma, beta, stats)
         ctx.relu = bool(relu)
@@ -818,7 +832,7 @@ class BNReluFn(torch.autograd.Function):
                                     stats[1].data_ptr(), dx.data_ptr(), dgb[0].data_ptr(), dgb[1].data_ptr(), ws.data_ptr(),
                                     int(ctx.relu), B, C, HW, _stream())
         _lib.check(rc, "mm_bn_relu_bwd")
-        return dx, dgb[0], dgb[1], None, None, None, None, None, None
+        return dx, dgb[0], dgb[1], None, None, None, None, None, None, None
 
 
 _DEFERRED_COUNTERS = None      # list while a caller batches the BatchNorm step counters of a whole forward (VSSM.forward_backbone)
@@ -858,7 +872,7 @@ class immediate_bn_counters:
         return False
 
 
-def bn_relu_train(x, bn, relu, partials=None):
+def bn_relu_train(x, bn, relu, partials=None, pre_bias=None):
     """`bn` (an nn.BatchNorm2d in training mode, affine, default momentum semantics) applied to x, optionally followed by
     ReLU, through BNReluFn; num_batches_tracked advances as in the module's own forward."""
     if bn.track_running_stats and bn.num_batches_tracked is not None:
@@ -870,7 +884,8 @@ def bn_relu_train(x, bn, relu, partials=None):
     else:
         momentum = 0.0 if bn.momentum is None else bn.momentum
     rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
-    y = BNReluFn.apply(x, bn.weight, bn.bias, rm, rv, bn.eps, momentum, relu, partials)
+    y = BNReluFn.apply(x, bn.weight, bn.bias, rm, rv, bn.eps, momentum, relu, partials,
+                       None if pre_bias is None else pre_bias.detach().float().contiguous())
     if rm is not None:
         # the kernel updated the running statistics through raw pointers: bump their version counters like an in-place torch
         # op would, so that anything keyed on them (SS_Conv_SSM._eval_fold) sees the change even if only the BatchNorm modules

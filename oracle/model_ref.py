@@ -152,10 +152,12 @@ def dt_rank(dim):
     return math.ceil((dim // 2) / 16)
 
 
-def shuffle_residual_ref(left_nchw, ssm, inp_nhwc, channel_first=False, ssm_scale=None, left_relu=False):
+def shuffle_residual_ref(left_nchw, ssm, inp_nhwc, channel_first=False, ssm_scale=None, left_relu=False, left_bias=None):
     """Test double for medmamba_amd.ops.shuffle_residual: the reference's own op chain, MedMamba.py:354-357 (with the
     trailing ReLU of the conv branch, :347, and the DropPath factor of :353 when they are handed over).
     channel_first: ssm is (B, C/2, H*W) instead of (B, H, W, C/2)."""
+    if left_bias is not None:                     # the closing 1x1 conv's bias (MedMamba.py:345), handed over by the caller
+        left_nchw = left_nchw + left_bias.reshape(1, -1, 1, 1)
     if left_relu:
         left_nchw = F.relu(left_nchw)
     left = left_nchw.permute(0, 2, 3, 1).contiguous()

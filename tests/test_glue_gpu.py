@@ -71,6 +71,19 @@ def test_shuffle_residual_forward_backward(shape):
         assert torch.equal(dev_in[1].grad.cpu(), gs)
         assert torch.equal(dev_in[0].grad.cpu(), ref_in[0].grad)
         assert torch.equal(dev_in[2].grad.cpu(), ref_in[2].grad)
+    # ... and the closing 1x1 conv's bias added in front of that ReLU (MedMamba.py:345): value, mask and the bias gradient
+    bias = torch.randn(C2, generator=g)
+    rb = bias.clone().requires_grad_()
+    ref_in = [t.clone().requires_grad_() for t in (left, ssm, inp)]
+    ref = shuffle_residual_ref(*ref_in, ssm_scale=scale, left_relu=True, left_bias=rb)
+    ref.backward(dout)
+    db = bias.to(DEV).requires_grad_()
+    dev_in = [left.to(DEV).requires_grad_(), ssm_cf.to(DEV).requires_grad_(), inp.to(DEV).requires_grad_()]
+    out = shuffle_residual(*dev_in, channel_first=True, ssm_scale=scale.to(DEV), left_relu=True, left_bias=db)
+    out.backward(dout.to(DEV))
+    assert (out.detach().cpu() - ref.detach()).abs().max().item() <= 1e-6
+    assert torch.equal(dev_in[0].grad.cpu(), ref_in[0].grad)
+    assert (db.grad.cpu() - rb.grad).abs().max().item() <= 1e-4 * max(1.0, rb.grad.abs().max().item())
 
 
 def test_in_proj_cf_forward_backward(layout):

@@ -227,9 +227,9 @@ def test_drop_path_factors_are_drawn_once_per_step(monkeypatch):
     seen = {}
     orig = modules.shuffle_residual
 
-    def spy(left, ssm, inp, channel_first=False, ssm_scale=None, left_relu=False):
+    def spy(left, ssm, inp, channel_first=False, ssm_scale=None, left_relu=False, left_bias=None):
         seen[len(seen)] = None if ssm_scale is None else ssm_scale.detach().clone()
-        return orig(left, ssm, inp, channel_first=channel_first, ssm_scale=ssm_scale, left_relu=left_relu)
+        return orig(left, ssm, inp, channel_first=channel_first, ssm_scale=ssm_scale, left_relu=left_relu, left_bias=left_bias)
 
     monkeypatch.setattr(modules, "shuffle_residual", spy)
     def no_own_draw(self, x):
@@ -308,9 +308,9 @@ def test_frozen_block_and_full_drop_rate(monkeypatch):
     seen = []
     orig = modules.shuffle_residual
 
-    def spy(left, ssm, inp, channel_first=False, ssm_scale=None, left_relu=False):
+    def spy(left, ssm, inp, channel_first=False, ssm_scale=None, left_relu=False, left_bias=None):
         seen.append(None if ssm_scale is None else ssm_scale.detach().clone())
-        return orig(left, ssm, inp, channel_first=channel_first, ssm_scale=ssm_scale, left_relu=left_relu)
+        return orig(left, ssm, inp, channel_first=channel_first, ssm_scale=ssm_scale, left_relu=left_relu, left_bias=left_bias)
 
     monkeypatch.setattr(modules, "shuffle_residual", spy)
     out = net(torch.randn(8, 3, 32, 32, device=DEV))

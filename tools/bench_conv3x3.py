@@ -43,7 +43,7 @@ def main():
         stats = torch.empty(lib.mm_conv3x3_fwd_tiles(B, HW, HW), C, 3, device=dev)
         t_mi = timeit(lambda: torch.nn.functional.conv2d(x, w, b, padding=1))
         t_bn = timeit(lambda: lib.mm_bn_relu_fwd(y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), 1e-5, 0.1, None, None, z.data_ptr(),
-                                                 mean.data_ptr(), rstd.data_ptr(), ws.data_ptr(), 1, B, C, HW * HW, st))
+                                                 mean.data_ptr(), rstd.data_ptr(), ws.data_ptr(), None, 1, B, C, HW * HW, st))
         t_own = timeit(lambda: lib.mm_conv3x3_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), None, 0, y.data_ptr(), stats.data_ptr(),
                                                   B, C, C, HW, HW, st))
         t_ap = timeit(lambda: lib.mm_bn_relu_fwd_stats(y.data_ptr(), stats.data_ptr(), stats.shape[0], gamma.data_ptr(), beta.data_ptr(),
