@@ -580,6 +580,24 @@ inline int small_plane_grid(int nplanes) {     // 4 planes per workgroup and ite
 // ---- LayerNorm over channels (out_norm, MedMamba.py:300) + gate y*silu(z) (:301), channel-first ----------------
 // m, y: (batch, D, L) contiguous; z: planes with batch stride z_sb.  Thread layout: PW consecutive positions x TPP
 // channel chunks per wave (TPP = 64/PW lanes share a position and split D); statistics mu/rstd: (batch, L).
+// sum over the W lanes that share lane / W (W = 1..64, the low lane bits), every lane gets the sum: DPP inside the 16-lane
+// rows, v_permlane16/32_swap across them — no ds_bpermute (the generic __shfl_xor) on these hot paths
+template <int W>
+__device__ __forceinline__ float low_sum(float v) {
+  v = mm::group_sum<(W < 16 ? W : 16)>(v);
+  if constexpr (W >= 32) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+    const unsigned a = r[0], b = r[1];
+    v = __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
+  }
+  if constexpr (W >= 64) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+    const unsigned a = r[0], b = r[1];
+    v = __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
+  }
+  return v;
+}
+
 template <int PW>
 __device__ __forceinline__ float pos_sum(float v) {   // sum over the 64/PW lanes that share a position
 #pragma unroll
@@ -680,11 +698,8 @@ __global__ __launch_bounds__(256) void ln_gate_bwd_kernel(const float* __restric
       pb_ = dn;
     }
     // sum over the PW positions of this wave that share channel d (lanes with equal ck): xor over the low bits
-#pragma unroll
-    for (int s = 1; s < PW; s <<= 1) {
-      pg += __shfl_xor(pg, s);
-      pb_ += __shfl_xor(pb_, s);
-    }
+    pg = low_sum<PW>(pg);
+    pb_ = low_sum<PW>(pb_);
     if ((lane % PW) == 0 && d < D) {
       sred[wv * 2 * D + d] = pg;
       sred[wv * 2 * D + D + d] = pb_;
@@ -805,11 +820,8 @@ __global__ __launch_bounds__(256) void ln_gate_bwd1_kernel(const float* __restri
       pb_ = dn;
     }
     // sum over the PW positions of this wave that share channel d (lanes with equal ck): xor over the low bits
-#pragma unroll
-    for (int s_ = 1; s_ < PW; s_ <<= 1) {
-      pg += __shfl_xor(pg, s_);
-      pb_ += __shfl_xor(pb_, s_);
-    }
+    pg = low_sum<PW>(pg);
+    pb_ = low_sum<PW>(pb_);
     if ((lane % PW) == 0 && d < D) {
       sred[wv * 2 * D + d] = pg;
       sred[wv * 2 * D + D + d] = pb_;
@@ -945,11 +957,8 @@ __global__ __launch_bounds__(NW * 64) void ln_gate_bwdc_kernel(const float* __re
       pb_ = dn;
     }
     // sum over the PW positions of this wave that share channel d (lanes with equal lane / PW): xor over the low bits
-#pragma unroll
-    for (int s_ = 1; s_ < PW; s_ <<= 1) {
-      pg += __shfl_xor(pg, s_);
-      pb_ += __shfl_xor(pb_, s_);
-    }
+    pg = low_sum<PW>(pg);
+    pb_ = low_sum<PW>(pb_);
     if (pl == 0 && d < D) {          // every channel belongs to exactly one (wave, lane group): plain stores would do, too
       sred[d] = pg;
       sred[D + d] = pb_;
