@@ -301,6 +301,14 @@ int mm_conv3x3_fwd_tiles(int batch, int H, int W);
 int mm_conv3x3_fwd(const float* x, const float* w, const float* bias, const float* in_affine, int in_relu, float* y, float* stats,
                    int batch, int C, int K, int H, int W, void* stream);
 
+/* Second version of the same convolution (finer tiles with the two halves of the input channels accumulated by different waves
+ * of a workgroup, raw-patch staging): `wt` is the weight PRE-TRANSPOSED to (C*9, K), wt[(c*9 + r*3 + s)*K + k] = w[k,c,r,s]
+ * (K % 4 == 0, 16-B aligned).  Passing wt built from the spatially flipped, channel-swapped weight and dy as x gives the data
+ * gradient.  stats: (mm_conv3x3_v2_tiles(batch, H, W), K, 3). */
+int mm_conv3x3_v2_tiles(int batch, int H, int W);
+int mm_conv3x3_v2_fwd(const float* x, const float* wt, const float* bias, const float* in_affine, int in_relu, float* y, float* stats,
+                      int batch, int C, int K, int H, int W, void* stream);
+
 /* SS2D parameters (MedMamba.py:150-175) -> one buffer in kernel direction order, A = -exp(A_logs) (MedMamba.py:271):
  *   x_proj_w (4, C, D), dt_w (4, D, R), dt_b (4, D), A_logs (4*D, N), Ds (4*D) in the reference's direction order
  *   k = (row fwd, col fwd, row rev, col rev);  packed = [Wx 4*C*D | Wdt 4*D*R | A 4*D*N | D 4*D | bias 4*D] floats

@@ -537,9 +537,10 @@ def test_small_planes_ignore_the_strip_knob():
 
 
 @pytest.mark.parametrize("shape", [(64, 192, 192, 14, 14), (2, 5, 7, 6, 9), (3, 48, 48, 56, 56), (5, 384, 384, 7, 7), (1, 8, 64, 1, 1),
-                                   (2, 70, 130, 11, 3)])
+                                   (2, 70, 132, 11, 3), (2, 20, 8, 28, 28), (1, 16, 32, 5, 100)])
 @pytest.mark.parametrize("mode", ["plain", "affine_relu", "nobias"])
-def test_own_conv3x3_forward_vs_fp64(shape, mode):
+@pytest.mark.parametrize("version", [1, 2])
+def test_own_conv3x3_forward_vs_fp64(shape, mode, version):
     """csrc/conv.hip (fp32 MFMA implicit-GEMM 3x3 conv, MedMamba.py:339, 342): output against an fp64 convolution, the optional
     input affine + ReLU (a BatchNorm folded in front, zero padding AFTER it), and the (count, mean, M2) partials of the epilogue
     merged by mm_bn_relu_fwd_stats against torch.nn.BatchNorm2d on the same conv output."""
@@ -552,9 +553,17 @@ def test_own_conv3x3_forward_vs_fp64(shape, mode):
     aff = torch.cat([torch.rand(C, device=DEV, generator=g) + 0.5, torch.randn(C, device=DEV, generator=g) * 0.3]) if mode == "affine_relu" else None
     lib = _lib.lib()
     y = torch.empty(B, K, H, W, device=DEV)
-    stats = torch.empty(lib.mm_conv3x3_fwd_tiles(B, H, W), K, 3, device=DEV)
-    rc = lib.mm_conv3x3_fwd(x.data_ptr(), w.data_ptr(), None if b is None else b.data_ptr(), None if aff is None else aff.data_ptr(),
-                            int(aff is not None), y.data_ptr(), stats.data_ptr(), B, C, K, H, W, torch.cuda.current_stream().cuda_stream)
+    if version == 1:
+        stats = torch.empty(lib.mm_conv3x3_fwd_tiles(B, H, W), K, 3, device=DEV)
+        rc = lib.mm_conv3x3_fwd(x.data_ptr(), w.data_ptr(), None if b is None else b.data_ptr(), None if aff is None else aff.data_ptr(),
+                                int(aff is not None), y.data_ptr(), stats.data_ptr(), B, C, K, H, W, torch.cuda.current_stream().cuda_stream)
+    else:
+        if K % 4:
+            pytest.skip("the second version needs K % 4 == 0")
+        wt = w.permute(1, 2, 3, 0).reshape(C * 9, K).contiguous()
+        stats = torch.empty(lib.mm_conv3x3_v2_tiles(B, H, W), K, 3, device=DEV)
+        rc = lib.mm_conv3x3_v2_fwd(x.data_ptr(), wt.data_ptr(), None if b is None else b.data_ptr(), None if aff is None else aff.data_ptr(),
+                                   int(aff is not None), y.data_ptr(), stats.data_ptr(), B, C, K, H, W, torch.cuda.current_stream().cuda_stream)
     assert rc == 0
     xin = x.double()
     if aff is not None:
