@@ -237,6 +237,7 @@ __global__ __launch_bounds__(256) void conv3x3_v2_kernel(const Conv2Params p) {
   const rsrc_t rx = make_rsrc(p.x, (int64_t)p.batch * p.C * p.HW * 4);
   const rsrc_t rw = make_rsrc(p.wt, (int64_t)p.C * 9 * p.K * 4);
   const int nslots = p.NR * W2;
+  const int nsl = (nslots + 127) >> 7;
   int sl_lds[4], sl_glb[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -254,25 +255,18 @@ __global__ __launch_bounds__(256) void conv3x3_v2_kernel(const Conv2Params p) {
 
   float xr[V2_CK][4];
   float4 wr[5];
+  // load_chunk ONLY issues loads (nothing consumes a loaded value here: any use — e.g. the optional input affine — would make
+  // the compiler wait for the load right there, in front of the MFMA loop that is supposed to hide its latency); the values
+  // are finished (affine, ReLU, padding mask) when store_chunk writes them to LDS one MFMA loop later
   auto load_chunk = [&](int c0) {
 #pragma unroll
     for (int ci = 0; ci < V2_CK; ++ci) {
       const int c = c0 + ci;
-      const bool cok = c < c_end;
       const int coff = c * p.HW * 4;
-      float sc = 1.f, sh = 0.f;
-      if (p.aff != nullptr) { sc = p.aff[cok ? c : 0]; sh = p.aff[p.C + (cok ? c : 0)]; }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const bool ok = cok && sl_glb[i] != kOOB;
-        float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, ok ? sl_glb[i] + coff : kOOB, 0, 0));
-        if (p.aff != nullptr) {
-          v = fmaf(v, sc, sh);
-          if (p.relu) v = fmaxf(v, 0.f);
-          v = ok ? v : 0.f;
-        }
-        xr[ci][i] = v;
-      }
+      for (int i = 0; i < 4; ++i)
+        if (i < nsl)          // (workgroup-uniform: slots in use for this plane width — 1 at 14x14 / 7x7, 2 at 28x28, 3 at 56x56)
+          xr[ci][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, (c < c_end && sl_glb[i] != kOOB) ? sl_glb[i] + coff : kOOB, 0, 0));
     }
 #pragma unroll
     for (int i = 0; i < 5; ++i) {                      // 72 rows x 8 quads = 576 quads per group of 128 threads
@@ -285,12 +279,26 @@ __global__ __launch_bounds__(256) void conv3x3_v2_kernel(const Conv2Params p) {
       wr[i] = make_float4(f.x, f.y, f.z, f.w);
     }
   };
-  auto store_chunk = [&]() {
+  auto store_chunk = [&](int c0) {
 #pragma unroll
-    for (int ci = 0; ci < V2_CK; ++ci)
+    for (int ci = 0; ci < V2_CK; ++ci) {
+      const int c = c0 + ci;
+      const bool cok = c < c_end;
+      float sc = 1.f, sh = 0.f;
+      if (p.aff != nullptr) { sc = p.aff[cok ? c : 0]; sh = p.aff[p.C + (cok ? c : 0)]; }
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        if (sl_lds[i] >= 0) sP[ci * p.PS + sl_lds[i]] = xr[ci][i];
+      for (int i = 0; i < 4; ++i) {
+        if (i >= nsl) continue;
+        float v = xr[ci][i];
+        if (p.aff != nullptr) {
+          v = fmaf(v, sc, sh);
+          if (p.relu & 1) v = fmaxf(v, 0.f);
+          v = (cok && sl_glb[i] != kOOB) ? v : 0.f;     // the padding is zero AFTER the affine (it pads the BatchNorm's output)
+        }
+        // slots beyond the patch go to a scratch word behind it instead of branching around the store
+        sP[ci * p.PS + (sl_lds[i] >= 0 ? sl_lds[i] : (p.NR + 1) * W2 - 1)] = (sl_lds[i] >= 0) ? v : 0.f;
+      }
+    }
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
       const int q = tg + 128 * i;
@@ -305,13 +313,27 @@ __global__ __launch_bounds__(256) void conv3x3_v2_kernel(const Conv2Params p) {
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 
-  if (nchunks > 0) load_chunk(c_begin);
+  const bool dbg_noload = p.relu & 2, dbg_nomfma = p.relu & 4;      // timing-only ablations (results are wrong when set)
+  if (dbg_noload) {
+#pragma unroll
+    for (int ci = 0; ci < V2_CK; ++ci)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xr[ci][i] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) wr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  } else {
+#pragma unroll
+    for (int ci = 0; ci < V2_CK; ++ci)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xr[ci][i] = 0.f;
+  }
+  if (nchunks > 0 && !dbg_noload) load_chunk(c_begin);
   const int nch_max = (((p.C + 15) / 16) * 8 + V2_CK - 1) / V2_CK;      // both halves run the same number of barriers
   for (int ch = 0; ch < nch_max; ++ch) {
-    if (ch < nchunks) store_chunk();
+    if (ch < nchunks) store_chunk(c_begin + ch * V2_CK);
     __syncthreads();
-    if (ch + 1 < nchunks) load_chunk(c_begin + (ch + 1) * V2_CK);
-    if (ch < nchunks) {
+    if (ch + 1 < nchunks && !dbg_noload) load_chunk(c_begin + (ch + 1) * V2_CK);
+    if (ch < nchunks && !dbg_nomfma) {
       // operands of the NEXT channel pair (9 taps: 9 A + 9 B registers) are read from LDS while the 9 MFMAs of the current one
       // run — left to itself the compiler emits read, s_waitcnt lgkmcnt(0), mfma per step and the matrix pipe idles for every
       // LDS round trip (measured: 32 % of the MFMA rate)
