@@ -319,12 +319,17 @@ int mm_conv3x3_v2_fwd(const float* x, const float* wt, const float* bias, const 
  *   nparts > 0: the A / D / bias segments of the gradient are NOT taken from dpacked but summed (fixed order, no atomics) over
  *   parts[q * S + (i - offset of the A segment)], q < nparts, S = mm_ss2d_pack_parts_size — the per-batch-item partial
  *   buffers mm_scan_bwd writes with mm_scan_args.dpar_sb = S, dA = parts, dD = parts + (D segment offset - A segment offset),
- *   ddelta_bias likewise.  nparts = 0 (parts may be NULL): everything from dpacked, as before ABI 19. */
+ *   ddelta_bias likewise.  nparts = 0 (parts may be NULL): everything from dpacked, as before ABI 19.
+ *   Two more small reductions of the SS2D backward can ride on the same launch (both optional, NULL = skip):
+ *   ln_ws (ln_rows, 2*D) = the partial rows mm_ln_gate_bwd wrote -> ln_out[2*D] = dgamma | dbeta of out_norm;
+ *   dw_ws (dw_batch, D*dw_strips, 10) = the partial sums mm_dwconv_silu_cross_bwd wrote -> dw_out[D*9 | D] = the depthwise conv's
+ *   weight gradient in (D,1,3,3) order followed by its bias gradient.  Fixed summation order (no atomics). */
 int mm_ss2d_pack_size(int D, int C, int R, int N);
 int mm_ss2d_pack_fwd(const float* x_proj_w, const float* dt_w, const float* dt_b, const float* A_logs, const float* Ds,
                      float* packed, int D, int C, int R, int N, void* stream);
 int mm_ss2d_pack_bwd(const float* dpacked, const float* packed, const float* parts, float* grads, int D, int C, int R, int N,
-                     int nparts, void* stream);
+                     int nparts, const float* ln_ws, int ln_rows, float* ln_out, const float* dw_ws, int dw_batch, int dw_strips,
+                     float* dw_out, void* stream);
 /* floats per part of `parts` = size of the [A | D | bias] tail of the packed layout (incl. its padding) */
 int mm_ss2d_pack_parts_size(int D, int C, int R, int N);
 

@@ -94,7 +94,8 @@ SYMBOLS = {
     "mm_channel_sum_nchw": (ctypes.c_int, [_f32p, _f32p] + [ctypes.c_int] * 3 + [ctypes.c_void_p]),
     "mm_ss2d_pack_size": (ctypes.c_int, [ctypes.c_int] * 4),
     "mm_ss2d_pack_fwd": (ctypes.c_int, [_f32p] * 6 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
-    "mm_ss2d_pack_bwd": (ctypes.c_int, [_f32p] * 4 + [ctypes.c_int] * 5 + [ctypes.c_void_p]),
+    "mm_ss2d_pack_bwd": (ctypes.c_int, [_f32p] * 4 + [ctypes.c_int] * 5 + [_f32p, ctypes.c_int, _f32p, _f32p, ctypes.c_int, ctypes.c_int,
+                                                                              _f32p, ctypes.c_void_p]),
     "mm_ss2d_pack_parts_size": (ctypes.c_int, [ctypes.c_int] * 4),
 }
 

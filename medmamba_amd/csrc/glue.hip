@@ -1466,11 +1466,61 @@ __host__ __device__ __forceinline__ PackSeg pack_layout(int D, int C, int R, int
 // direction of segment s (computed on the host).
 struct PackGrid { int blk_off[6]; int nb[5]; };
 
+// Small reductions of the SS2D backward that ride on the un-packing launch (mm_ss2d_pack_bwd): the per-workgroup partial rows of
+// ln_gate_bwd (dgamma | dbeta of out_norm) and the per-(plane, strip) partial sums of the depthwise conv's weight / bias
+// gradient, written in their final contiguous layouts behind the packed gradients — 2 reduction launches and 2 layout copies per
+// block less on the main stream.
+struct PackExtra {
+  const float* ln_ws;      // (ln_rows, 2*D) or nullptr
+  const float* dw_ws;      // (batch, D*S, 10) or nullptr
+  float* ln_out;           // 2*D: dgamma | dbeta
+  float* dw_out;           // D*9 (weight gradient, (D,1,3,3) order) | D (bias gradient)
+  int ln_rows, dw_batch, dw_S, blk_ln, blk_dw;    // blocks [blk_ln, blk_dw) reduce ln_ws, [blk_dw, grid) reduce dw_ws
+};
+
+__device__ __forceinline__ void pack_extra_blocks(const PackExtra& ex, int D, float* red) {
+  const int b = blockIdx.x;
+  if (b < ex.blk_dw) {
+    // ln: block = 64 columns x 4 row lanes; rows strided by 4, then 4 -> 1 through LDS (fixed order)
+    const int col = (b - ex.blk_ln) * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+    float a0 = 0.f, a1 = 0.f;
+    if (col < 2 * D) {
+      const float* src = ex.ln_ws + col;
+      int r = rl;
+      for (; r + 4 < ex.ln_rows; r += 8) { a0 += src[(int64_t)r * 2 * D]; a1 += src[(int64_t)(r + 4) * 2 * D]; }
+      if (r < ex.ln_rows) a0 += src[(int64_t)r * 2 * D];
+    }
+    red[threadIdx.x] = a0 + a1;
+    __syncthreads();
+    if (rl == 0 && col < 2 * D) ex.ln_out[col] = (red[threadIdx.x] + red[threadIdx.x + 64]) + (red[threadIdx.x + 128] + red[threadIdx.x + 192]);
+  } else {
+    // depthwise conv: thread = (channel d, j of 10); sums over batch and strips in a fixed order
+    const int o = (b - ex.blk_dw) * 256 + threadIdx.x;
+    if (o < D * 10) {
+      const int d = o / 10, j = o - d * 10;
+      const int64_t bstride = (int64_t)D * ex.dw_S * 10;
+      float a0 = 0.f, a1 = 0.f;
+      for (int s = 0; s < ex.dw_S; ++s) {
+        const float* src = ex.dw_ws + ((int64_t)d * ex.dw_S + s) * 10 + j;
+        int q = 0;
+        for (; q + 1 < ex.dw_batch; q += 2) { a0 += src[q * bstride]; a1 += src[(q + 1) * bstride]; }
+        if (q < ex.dw_batch) a0 += src[q * bstride];
+      }
+      const float v = a0 + a1;
+      if (j < 9) ex.dw_out[d * 9 + j] = v; else ex.dw_out[D * 9 + d] = v;
+    }
+  }
+}
+
 template <bool BWD>
 __global__ __launch_bounds__(256) void ss2d_pack_kernel(const float* __restrict__ s0, const float* __restrict__ s1,
                                                         const float* __restrict__ s2, const float* __restrict__ s3,
                                                         const float* __restrict__ s4, float* __restrict__ dst, int D, int C,
-                                                        int R, int N, PackGrid pg, int nparts) {
+                                                        int R, int N, PackGrid pg, int nparts, PackExtra ex) {
+  if constexpr (BWD) {
+    __shared__ float red[256];
+    if ((int)blockIdx.x >= ex.blk_ln) { pack_extra_blocks(ex, D, red); return; }
+  }
   // no runtime-indexed local arrays here: they would live in scratch memory, and a dispatch that needs scratch costs
   // ~12 us of set-up on top of a 2 us kernel (measured)
   const int b = blockIdx.x;
@@ -1537,8 +1587,10 @@ int mm_ss2d_pack_fwd(const float* x_proj_w, const float* dt_w, const float* dt_b
   if (!x_proj_w || !dt_w || !dt_b || !A_logs || !Ds || !packed) return MM_ERR_NULL;
   if (D <= 0 || C <= 0 || R <= 0 || N <= 0) return MM_ERR_SHAPE;
   const PackGrid pg = pack_grid(D, C, R, N);
+  PackExtra ex{};
+  ex.blk_ln = ex.blk_dw = pg.blk_off[5];
   hipLaunchKernelGGL(ss2d_pack_kernel<false>, dim3(pg.blk_off[5]), dim3(256), 0, (hipStream_t)stream, x_proj_w, dt_w, dt_b,
-                     A_logs, Ds, packed, D, C, R, N, pg, 0);
+                     A_logs, Ds, packed, D, C, R, N, pg, 0, ex);
   return (int)hipGetLastError();
 }
 
@@ -1548,12 +1600,20 @@ int mm_ss2d_pack_parts_size(int D, int C, int R, int N) {
 }
 
 int mm_ss2d_pack_bwd(const float* dpacked, const float* packed, const float* parts, float* grads, int D, int C, int R, int N,
-                     int nparts, void* stream) {
+                     int nparts, const float* ln_ws, int ln_rows, float* ln_out, const float* dw_ws, int dw_batch, int dw_strips,
+                     float* dw_out, void* stream) {
   if (!dpacked || !packed || !grads || (nparts > 0 && !parts)) return MM_ERR_NULL;
   if (D <= 0 || C <= 0 || R <= 0 || N <= 0 || nparts < 0) return MM_ERR_SHAPE;
+  if ((ln_ws && (!ln_out || ln_rows <= 0)) || (dw_ws && (!dw_out || dw_batch <= 0 || dw_strips <= 0))) return MM_ERR_SHAPE;
   const PackGrid pg = pack_grid(D, C, R, N);
-  hipLaunchKernelGGL(ss2d_pack_kernel<true>, dim3(pg.blk_off[5]), dim3(256), 0, (hipStream_t)stream, dpacked, packed, parts,
-                     nullptr, nullptr, grads, D, C, R, N, pg, nparts);
+  PackExtra ex{};
+  ex.ln_ws = ln_ws; ex.ln_rows = ln_rows; ex.ln_out = ln_out;
+  ex.dw_ws = dw_ws; ex.dw_batch = dw_batch; ex.dw_S = dw_strips; ex.dw_out = dw_out;
+  ex.blk_ln = pg.blk_off[5];
+  ex.blk_dw = ex.blk_ln + (ln_ws ? (2 * D + 63) / 64 : 0);
+  const int grid = ex.blk_dw + (dw_ws ? (D * 10 + 255) / 256 : 0);
+  hipLaunchKernelGGL(ss2d_pack_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, dpacked, packed, parts,
+                     nullptr, nullptr, grads, D, C, R, N, pg, nparts, ex);
   return (int)hipGetLastError();
 }
 

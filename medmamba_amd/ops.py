@@ -24,6 +24,7 @@ def _need_hip(*ts):
 #                good split-K for K = B*L ~ 2e5), hence channel-major only for short sequences.
 # Every plane kernel takes (batch stride, channel stride), so both layouts run the same code.
 _LAYOUT = os.environ.get("MM_LAYOUT", "auto")          # "auto" | "bm" | "cm" (tests force both)
+_PACK_FOLD = os.environ.get("MM_PACK_FOLD", "1") == "1"  # the SS2D backward's small reductions ride on mm_ss2d_pack_bwd (0: ATen sums)
 _FUSE_DT = os.environ.get("MM_FUSE_DT", "1") == "1"     # inference: dt projection inside the scan kernel (MM_FUSE_DT=0: always a GEMM)
 
 
@@ -386,7 +387,7 @@ class SS2DCoreFn(torch.autograd.Function):
             d1 = dout2[:, D:]
             rc = lib.mm_plane_transpose(*_pl(dout2), *_pl(d1), Bsz, D, H, W, _stream())
             _lib.check(rc, "mm_plane_transpose")
-        wsum = ws.sum(0)
+        # (the rows of ws are summed by mm_ss2d_pack_bwd below, together with the depthwise conv's partial sums)
         # gradient of the packed parameters: the GEMMs below write the two weight segments of dP; the A / D / bias segments come
         # from per-batch-item partial buffers that the scan kernel fills with plain stores and mm_ss2d_pack_bwd sums in a
         # fixed order (no atomics, no zero-fill: bitwise reproducible)
@@ -435,24 +436,40 @@ class SS2DCoreFn(torch.autograd.Function):
                 du2.baddbmm_(WxT, dxd2.reshape(Bsz * 2, 2 * C, L))                               # + Wx^T d(x_dbl)
             torch.sum(torch.matmul(dxd2, u2.view(Bsz, 2, D, L).transpose(-1, -2)), 0, out=dWx.view(2, 2 * C, D))
             du2 = du2.view(Bsz, 2 * D, L)
-        G = torch.empty_like(P)
-        with _lib.device_guard(dev):
-            rc = lib.mm_ss2d_pack_bwd(dP.data_ptr(), P.data_ptr(), parts.data_ptr(), G.data_ptr(), D, C, R, N, Bsz, _stream())
-        _lib.check(rc, "mm_ss2d_pack_bwd")
-        gWx, gWdt, gA, gD, gb = SS2DCoreFn._segments(G, D, C, R, N)
-        dcw = dcb = None
+        dcw = dcb = wsc = None
+        strips = 0
         if fused_conv:
             # d(u2) = projection part (du2) + the scan's two direction pairs (du4), summed inside the conv's backward kernel
             dxc = dxz[:, :D]
-            wsc = torch.empty((Bsz, D * lib.mm_dwconv_silu_cross_strips(H, W), 10), device=dev, dtype=torch.float32)
+            strips = lib.mm_dwconv_silu_cross_strips(H, W)
+            wsc = torch.empty((Bsz, D * strips, 10), device=dev, dtype=torch.float32)
             with _lib.device_guard(dev):
                 rc = lib.mm_dwconv_silu_cross_bwd(*_pl(du2), *_pl(du4), *_pl(x_cf), conv_w.data_ptr(),
                                                   None if conv_b is None else conv_b.data_ptr(), *_pl(dxc), wsc.data_ptr(),
                                                   Bsz, D, H, W, _stream())
             _lib.check(rc, "mm_dwconv_silu_cross_bwd")
-            sc = wsc.view(Bsz, D, -1, 10).sum((0, 2))
-            du2, dcw, dcb = dxc, sc[:, :9].reshape(D, 1, 3, 3), (None if conv_b is None else sc[:, 9])
-        return (du2, dcw, dcb, gWx, gWdt, gb.view(4, D), gA, gD, dz, wsum[:D], wsum[D:], None, None, None, None)
+            du2 = dxc
+        # one launch: packed gradients back to the module's parameter layouts (A / D / bias summed over the batch partials), the
+        # rows of ln_gate's ws -> d(out_norm weight | bias), the depthwise conv's partial sums -> d(conv weight | bias)
+        npk = P.numel()
+        G = torch.empty((npk + 2 * D + 10 * D,), device=dev, dtype=torch.float32)
+        ln_out, dw_out = G[npk:npk + 2 * D], G[npk + 2 * D:]
+        fold = _PACK_FOLD
+        with _lib.device_guard(dev):
+            rc = lib.mm_ss2d_pack_bwd(dP.data_ptr(), P.data_ptr(), parts.data_ptr(), G.data_ptr(), D, C, R, N, Bsz,
+                                      ws.data_ptr() if fold else None, ws.shape[0], ln_out.data_ptr(),
+                                      None if (wsc is None or not fold) else wsc.data_ptr(), Bsz, strips,
+                                      None if wsc is None else dw_out.data_ptr(), _stream())
+        _lib.check(rc, "mm_ss2d_pack_bwd")
+        gWx, gWdt, gA, gD, gb = SS2DCoreFn._segments(G[:npk], D, C, R, N)
+        if not fold:                                  # A/B switch (MM_PACK_FOLD=0): the reductions as separate ATen launches
+            ln_out = ws.sum(0)
+            if wsc is not None:
+                sc = wsc.view(Bsz, D, -1, 10).sum((0, 2))
+                dw_out = torch.cat([sc[:, :9].reshape(-1), sc[:, 9]])
+        if fused_conv:
+            dcw, dcb = dw_out[:9 * D].view(D, 1, 3, 3), (None if conv_b is None else dw_out[9 * D:])
+        return (du2, dcw, dcb, gWx, gWdt, gb.view(4, D), gA, gD, dz, ln_out[:D], ln_out[D:], None, None, None, None)
 
 
 def ss2d_core(u2, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds, z_cf, ln_w, ln_b, H, W, eps=1e-5,
