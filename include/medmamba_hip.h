@@ -288,8 +288,13 @@ int mm_bn_relu_fwd(const float* x, const float* gamma, const float* beta, float 
 int mm_bn_relu_fwd_stats(const float* x, const float* partials, int nparts, const float* gamma, const float* beta, float eps,
                          float momentum, float* running_mean, float* running_var, float* y, float* mean, float* rstd, int relu,
                          int batch, int C, int HW, void* stream);
+/* mm_bn_fused(batch, C, HW) = 1 when both directions run as ONE kernel with a whole channel in one workgroup's registers
+ * (batch*HW <= 16384, C >= 64: the 14x14 / 7x7 stages; ws is not touched then).  Only that form can also return
+ * dxsum (C) = the per-channel sum of dx — the bias gradient of the convolution that produced x (MedMamba.py:339, 342) —
+ * pass NULL otherwise (MM_ERR_UNSUPPORTED if asked for with the two-kernel form). */
+int mm_bn_fused(int batch, int C, int HW);
 int mm_bn_relu_bwd(const float* dy, const float* x, const float* gamma, const float* beta, const float* mean, const float* rstd,
-                   float* dx, float* dgamma, float* dbeta, float* ws, int relu, int batch, int C, int HW, void* stream);
+                   float* dx, float* dgamma, float* dbeta, float* ws, float* dxsum, int relu, int batch, int C, int HW, void* stream);
 
 /* Dense 3x3 convolution, padding 1, stride 1, of the conv branch (MedMamba.py:339, 342), forward, fp32 on the matrix cores:
  *   y[b,k,h,w] = bias[k] + sum_{c,r,s} w[k,c,r,s] * x'[b,c,h+r-1,w+s-1];  x, y contiguous NCHW, w (K, C, 3, 3), bias (K) or NULL.

@@ -89,7 +89,8 @@ SYMBOLS = {
     "mm_conv3x3_fwd": (ctypes.c_int, [_f32p] * 4 + [ctypes.c_int, _f32p, _f32p] + [ctypes.c_int] * 5 + [ctypes.c_void_p]),
     "mm_conv3x3_v2_tiles": (ctypes.c_int, [ctypes.c_int] * 3),
     "mm_conv3x3_v2_fwd": (ctypes.c_int, [_f32p] * 4 + [ctypes.c_int, _f32p, _f32p] + [ctypes.c_int] * 5 + [ctypes.c_void_p]),
-    "mm_bn_relu_bwd": (ctypes.c_int, [_f32p] * 10 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
+    "mm_bn_fused": (ctypes.c_int, [ctypes.c_int] * 3),
+    "mm_bn_relu_bwd": (ctypes.c_int, [_f32p] * 11 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
     "mm_channel_sum_nchw_split": (ctypes.c_int, [ctypes.c_int] * 2),
     "mm_channel_sum_nchw": (ctypes.c_int, [_f32p, _f32p] + [ctypes.c_int] * 3 + [ctypes.c_void_p]),
     "mm_ss2d_pack_size": (ctypes.c_int, [ctypes.c_int] * 4),

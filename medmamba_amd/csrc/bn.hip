@@ -12,6 +12,7 @@
 // Semantics = torch.nn.BatchNorm2d in training mode: biased variance for the normalisation, unbiased for running_var,
 // running = (1 - momentum) * running + momentum * batch.  The ReLU mask in the backward is recomputed from x with the forward's
 // own expression fmaf(x, rstd*gamma, beta - mean*rstd*gamma) (y is not read).
+#include <stdlib.h>
 #include "mm_common.h"
 #include "medmamba_hip.h"
 
@@ -201,6 +202,101 @@ __global__ __launch_bounds__(256) void bn_apply_bwd_kernel(const float* __restri
   }
 }
 
+// ---- one workgroup per channel, the whole channel in registers (batch * HW <= 512 * VPT): statistics and apply in ONE pass over
+// HBM and ONE launch — the 14x14 / 7x7 stages, where the two-kernel form is bound by launch latency (12.7 + 10.4 us for 9.6 MB).
+__device__ __forceinline__ float block_sum512(float v, float* red) {     // sum over a 512-thread workgroup, result in every thread
+  v = group_sum<16>(v);
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 32);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[wv] = v;
+  __syncthreads();
+  return ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
+}
+
+template <int VPT>
+__global__ __launch_bounds__(512) void bn_fused_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float eps, float momentum,
+                                                           float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                           float* __restrict__ y, float* __restrict__ mean_out,
+                                                           float* __restrict__ rstd_out, int relu, const float* __restrict__ pre_bias,
+                                                           int batch, int C, int HW) {
+  __shared__ float red[8];
+  const int c = blockIdx.x, n = batch * HW;
+  float v[VPT];
+  int64_t off[VPT];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) {
+    const int e = threadIdx.x + 512 * i;
+    const int b = e / HW, p = e - b * HW;
+    off[i] = e < n ? ((int64_t)b * C + c) * HW + p : -1;
+    v[i] = off[i] >= 0 ? x[off[i]] : 0.f;
+    sum += v[i];
+  }
+  const float mean = block_sum512(sum, red) / (float)n;
+  float m2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) { const float d = off[i] >= 0 ? v[i] - mean : 0.f; m2 = fmaf(d, d, m2); }
+  m2 = block_sum512(m2, red);
+  const float var = m2 / (float)n;
+  const float rstd = 1.0f / sqrtf(var + eps);
+  const float sc = rstd * gamma[c], sh = beta[c] - mean * sc;
+  if (threadIdx.x == 0) {
+    mean_out[c] = mean; rstd_out[c] = rstd;
+    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (mean + (pre_bias ? pre_bias[c] : 0.f));
+    if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (n > 1 ? m2 / (float)(n - 1) : var);
+  }
+#pragma unroll
+  for (int i = 0; i < VPT; ++i)
+    if (off[i] >= 0) { const float o = fmaf(v[i], sc, sh); y[off[i]] = relu ? fmaxf(o, 0.f) : o; }
+}
+
+// dxsum (optional, C): per-channel sum of the dx written here = the bias gradient of the convolution that produced x
+template <int VPT>
+__global__ __launch_bounds__(512) void bn_fused_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                           const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta, int relu,
+                                                           float* __restrict__ dx, float* __restrict__ dgamma,
+                                                           float* __restrict__ dbeta, float* __restrict__ dxsum, int batch, int C, int HW) {
+  __shared__ float red[8];
+  const int c = blockIdx.x, n = batch * HW;
+  const float mean = mean_in[c], rstd = rstd_in[c], gm = gamma[c], bt = beta[c];
+  const float sc = rstd * gm, sh = bt - mean * sc;       // the forward's affine: same ReLU mask as the forward kernels
+  float gg[VPT], xh[VPT];
+  int64_t off[VPT];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) {
+    const int e = threadIdx.x + 512 * i;
+    const int b = e / HW, p = e - b * HW;
+    off[i] = e < n ? ((int64_t)b * C + c) * HW + p : -1;
+    const float xv = off[i] >= 0 ? x[off[i]] : 0.f;
+    const float d = off[i] >= 0 ? dy[off[i]] : 0.f;
+    xh[i] = (xv - mean) * rstd;
+    gg[i] = (off[i] < 0 || (relu && fmaf(xv, sc, sh) <= 0.f)) ? 0.f : d;
+    s1 += gg[i]; s2 = fmaf(gg[i], xh[i], s2);
+  }
+  s1 = block_sum512(s1, red);
+  s2 = block_sum512(s2, red);
+  const float inv_n = 1.f / (float)n;
+  const float m1 = s1 * inv_n, m2 = s2 * inv_n, k = gm * rstd;
+  float ds = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPT; ++i)
+    if (off[i] >= 0) { const float o = k * (gg[i] - m1 - xh[i] * m2); dx[off[i]] = o; ds += o; }
+  if (dxsum != nullptr) ds = block_sum512(ds, red);
+  if (threadIdx.x == 0) { dgamma[c] = s2; dbeta[c] = s1; if (dxsum != nullptr) dxsum[c] = ds; }
+}
+
+inline int bn_fused_vpt(int batch, int C, int HW) {        // 0: the two-kernel form
+  static const int enabled = [] { const char* e = getenv("MM_BN_FUSED"); return e ? atoi(e) : 1; }();   // A/B switch
+  const int64_t n = (int64_t)batch * HW;
+  if (!enabled || C < 64 || n > 512 * 32) return 0;
+  return n <= 512 * 8 ? 8 : n <= 512 * 16 ? 16 : 32;
+}
+
 inline BnGeom bn_geom(int batch, int C, int HW) {
   // batch slices: enough workgroups to fill the chip (>= ~1024), at least ~16 KB of a channel per workgroup
   int S = (1024 + C - 1) / C;
@@ -224,8 +320,17 @@ int mm_bn_relu_fwd(const float* x, const float* gamma, const float* beta, float 
   if (!x || !gamma || !beta || !y || !mean || !rstd || !ws) return MM_ERR_NULL;
   if (batch <= 0 || C <= 0 || HW <= 0) return MM_ERR_SHAPE;
   if ((int64_t)batch * HW < 2) return MM_ERR_SHAPE;          // (torch raises for a single value per channel as well)
-  const BnGeom g = bn_geom(batch, C, HW);
   hipStream_t s = (hipStream_t)stream;
+  switch (bn_fused_vpt(batch, C, HW)) {
+#define MM_BN_FF(V) hipLaunchKernelGGL(bn_fused_fwd_kernel<V>, dim3(C), dim3(512), 0, s, x, gamma, beta, eps, momentum, running_mean, \
+                                       running_var, y, mean, rstd, relu, pre_bias, batch, C, HW); return (int)hipGetLastError()
+    case 8: MM_BN_FF(8);
+    case 16: MM_BN_FF(16);
+    case 32: MM_BN_FF(32);
+#undef MM_BN_FF
+    default: break;
+  }
+  const BnGeom g = bn_geom(batch, C, HW);
   hipLaunchKernelGGL(bn_stats_kernel, dim3(C * g.S), dim3(256), 0, s, x, ws, g);
   hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3(C * g.S), dim3(256), 0, s, x, ws, gamma, beta, eps, momentum, running_mean, running_var, y, mean,
                      rstd, relu, pre_bias, g);
@@ -245,12 +350,25 @@ int mm_bn_relu_fwd_stats(const float* x, const float* partials, int nparts, cons
   return (int)hipGetLastError();
 }
 
+int mm_bn_fused(int batch, int C, int HW) { return (batch > 0 && C > 0 && HW > 0 && bn_fused_vpt(batch, C, HW) > 0) ? 1 : 0; }
+
 int mm_bn_relu_bwd(const float* dy, const float* x, const float* gamma, const float* beta, const float* mean, const float* rstd,
-                   float* dx, float* dgamma, float* dbeta, float* ws, int relu, int batch, int C, int HW, void* stream) {
+                   float* dx, float* dgamma, float* dbeta, float* ws, float* dxsum, int relu, int batch, int C, int HW, void* stream) {
   if (!dy || !x || !gamma || !beta || !mean || !rstd || !dx || !dgamma || !dbeta || !ws) return MM_ERR_NULL;
   if (batch <= 0 || C <= 0 || HW <= 0) return MM_ERR_SHAPE;
-  const BnGeom g = bn_geom(batch, C, HW);
   hipStream_t s = (hipStream_t)stream;
+  const int vpt = bn_fused_vpt(batch, C, HW);
+  if (dxsum != nullptr && vpt == 0) return MM_ERR_UNSUPPORTED;     // only the one-kernel form produces it (mm_bn_fused)
+  switch (vpt) {
+#define MM_BN_FB(V) hipLaunchKernelGGL(bn_fused_bwd_kernel<V>, dim3(C), dim3(512), 0, s, dy, x, mean, rstd, gamma, beta, relu, dx, dgamma, \
+                                       dbeta, dxsum, batch, C, HW); return (int)hipGetLastError()
+    case 8: MM_BN_FB(8);
+    case 16: MM_BN_FB(16);
+    case 32: MM_BN_FB(32);
+#undef MM_BN_FB
+    default: break;
+  }
+  const BnGeom g = bn_geom(batch, C, HW);
   hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3(C * g.S), dim3(256), 0, s, dy, x, mean, rstd, gamma, beta, relu, ws, g);
   hipLaunchKernelGGL(bn_apply_bwd_kernel, dim3(C * g.S), dim3(256), 0, s, dy, x, mean, rstd, gamma, beta, relu, ws, dx, dgamma, dbeta, g);
   return (int)hipGetLastError();

@@ -531,12 +531,12 @@ class ConvBiasFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, stride, padding, dilation, add_bias=True):
         # add_bias=False: the caller folds the bias into the BatchNorm that follows (ops.bn_relu_train(pre_bias=...)): y is the
-        # convolution WITHOUT bias (MIOpen adds a bias in a separate elementwise pass: 47 us at 64 x 48 x 56 x 56); the bias
-        # still gets its gradient (the channel sums of dy) below
+        # convolution WITHOUT bias (MIOpen adds a bias in a separate elementwise pass: 47 us at 64 x 48 x 56 x 56); the bias gets
+        # its gradient (the channel sums of this conv's dy = the BatchNorm's dx) from BNReluFn.backward
         y = torch.nn.functional.conv2d(x, w, b if add_bias else None, stride, padding, dilation)
         ctx.save_for_backward(x, w)
-        ctx.cfg = (list(stride), list(padding), list(dilation), b is not None)
-        return y
+        ctx.cfg = (list(stride), list(padding), list(dilation), b is not None and add_bias)     # deferred bias: its gradient comes
+        return y                                                                                 # from BNReluFn (pre_bias)
 
     @staticmethod
     def backward(ctx, dy):
@@ -807,6 +807,7 @@ class BNReluFn(torch.autograd.Function):
     def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, relu, partials=None, pre_bias=None):
         x = x.float().contiguous()
         gamma, beta = gamma.float().contiguous(), beta.float().contiguous()
+        pre_bias = None if pre_bias is None else pre_bias.float().contiguous()
         B, C = x.shape[0], x.shape[1]
         HW = x.numel() // (B * C)
         dev = x.device
@@ -831,6 +832,7 @@ class BNReluFn(torch.autograd.Function):
             _lib.check(rc, "mm_bn_relu_fwd")
         ctx.save_for_backward(x, gamma, beta, stats)
         ctx.relu = bool(relu)
+        ctx.has_pre_bias = pre_bias is not None
         return y
 
     @staticmethod
@@ -842,14 +844,21 @@ class BNReluFn(torch.autograd.Function):
         dy = dy.float().contiguous()
         lib = _lib.lib()
         dx = torch.empty_like(x)
-        dgb = torch.empty((2, C), device=dev, dtype=torch.float32)
-        ws = torch.empty((2 * C * lib.mm_bn_splits(B, C, HW),), device=dev, dtype=torch.float32)
+        # pre_bias is the bias of the convolution that produced x: its gradient is the per-channel sum of dx, which the
+        # one-kernel form (small planes) returns for free; larger planes take the channel-sum kernel
+        want_db = ctx.has_pre_bias and ctx.needs_input_grad[9]
+        fused = bool(lib.mm_bn_fused(B, C, HW))
+        dgb = torch.empty((3, C), device=dev, dtype=torch.float32)
+        ws = dgb if fused else torch.empty((2 * C * lib.mm_bn_splits(B, C, HW),), device=dev, dtype=torch.float32)
         with _lib.device_guard(dev):
             rc = lib.mm_bn_relu_bwd(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), stats[0].data_ptr(),
                                     stats[1].data_ptr(), dx.data_ptr(), dgb[0].data_ptr(), dgb[1].data_ptr(), ws.data_ptr(),
-                                    int(ctx.relu), B, C, HW, _stream())
+                                    dgb[2].data_ptr() if (want_db and fused) else None, int(ctx.relu), B, C, HW, _stream())
         _lib.check(rc, "mm_bn_relu_bwd")
-        return dx, dgb[0], dgb[1], None, None, None, None, None, None, None
+        db = None
+        if want_db:
+            db = dgb[2] if fused else _bias_grad(dx)
+        return dx, dgb[0], dgb[1], None, None, None, None, None, None, db
 
 
 _DEFERRED_COUNTERS = None      # list while a caller batches the BatchNorm step counters of a whole forward (VSSM.forward_backbone)
@@ -901,8 +910,7 @@ def bn_relu_train(x, bn, relu, partials=None, pre_bias=None):
     else:
         momentum = 0.0 if bn.momentum is None else bn.momentum
     rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
-    y = BNReluFn.apply(x, bn.weight, bn.bias, rm, rv, bn.eps, momentum, relu, partials,
-                       None if pre_bias is None else pre_bias.detach().float().contiguous())
+    y = BNReluFn.apply(x, bn.weight, bn.bias, rm, rv, bn.eps, momentum, relu, partials, pre_bias)
     if rm is not None:
         # the kernel updated the running statistics through raw pointers: bump their version counters like an in-place torch
         # op would, so that anything keyed on them (SS_Conv_SSM._eval_fold) sees the change even if only the BatchNorm modules
