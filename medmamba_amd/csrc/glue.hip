@@ -1248,14 +1248,16 @@ __device__ __forceinline__ float row_sum(float v) {
 
 constexpr int kLnNV = 8;   // channels per lane (C2 <= 8 * TPR)
 
+// (device bodies with a virtual block index / grid size: mm_block_split_* runs the transpose of the left half and the LayerNorm of
+//  the right half — independent of each other — as the two block ranges of ONE launch)
 template <int TPR>
-__global__ __launch_bounds__(256) void ln_half_fwd_kernel(const float* __restrict__ inp, const float* __restrict__ gamma,
-                                                          const float* __restrict__ beta, float eps, float* __restrict__ rn,
-                                                          float* __restrict__ mu_out, float* __restrict__ rstd_out,
-                                                          int64_t nrows, int C, int C2) {
+__device__ __forceinline__ void ln_half_fwd_body(int vblk, int vgrid, const float* __restrict__ inp, const float* __restrict__ gamma,
+                                                 const float* __restrict__ beta, float eps, float* __restrict__ rn,
+                                                 float* __restrict__ mu_out, float* __restrict__ rstd_out,
+                                                 int64_t nrows, int C, int C2) {
   constexpr int RPW = 64 / TPR;
   const int lane = threadIdx.x & 63, lr = lane % TPR;
-  const int64_t wave_global = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+  const int64_t wave_global = (int64_t)vblk * 4 + (threadIdx.x >> 6), nwaves = (int64_t)vgrid * 4;
   float gm[kLnNV], bt[kLnNV];
 #pragma unroll
   for (int k = 0; k < kLnNV; ++k) {
@@ -1295,14 +1297,14 @@ __global__ __launch_bounds__(256) void ln_half_fwd_kernel(const float* __restric
 
 // d_inp[row, C2 + c] = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = d_rn * gamma;  per-wave partial dgamma / dbeta rows.
 template <int TPR>
-__global__ __launch_bounds__(256) void ln_half_bwd_kernel(const float* __restrict__ drn, const float* __restrict__ inp,
-                                                          const float* __restrict__ gamma, const float* __restrict__ mu_in,
-                                                          const float* __restrict__ rstd_in, const float* __restrict__ dres,
-                                                          float* __restrict__ dinp, float* __restrict__ ws, int64_t nrows, int C,
-                                                          int C2) {
+__device__ __forceinline__ void ln_half_bwd_body(int vblk, int vgrid, const float* __restrict__ drn, const float* __restrict__ inp,
+                                                 const float* __restrict__ gamma, const float* __restrict__ mu_in,
+                                                 const float* __restrict__ rstd_in, const float* __restrict__ dres,
+                                                 float* __restrict__ dinp, float* __restrict__ ws, int64_t nrows, int C,
+                                                 int C2) {
   constexpr int RPW = 64 / TPR;
   const int lane = threadIdx.x & 63, lr = lane % TPR;
-  const int64_t wave_global = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+  const int64_t wave_global = (int64_t)vblk * 4 + (threadIdx.x >> 6), nwaves = (int64_t)vgrid * 4;
   float gm[kLnNV], ag[kLnNV], ab[kLnNV];
 #pragma unroll
   for (int k = 0; k < kLnNV; ++k) {
@@ -1350,19 +1352,19 @@ __global__ __launch_bounds__(256) void ln_half_bwd_kernel(const float* __restric
   }
   __syncthreads();
   for (int i = threadIdx.x; i < 2 * C2; i += blockDim.x)
-    ws[(int64_t)blockIdx.x * 2 * C2 + i] = (sred[i] + sred[2 * C2 + i]) + (sred[4 * C2 + i] + sred[6 * C2 + i]);
+    ws[(int64_t)vblk * 2 * C2 + i] = (sred[i] + sred[2 * C2 + i]) + (sred[4 * C2 + i] + sred[6 * C2 + i]);
 }
 
 // dst[b, i, p] = src[b, p, i] for i < C2 (src row stride C): NHWC half -> NCHW.  REV: the other way round
 // (dst[b, p, i] = src[b, i, p] written into a buffer with row stride C).  grid: ceil(P/32) * ceil(C2/32) * batch
 // REV only: `add` (same layout as dst, or null) is added to what is written (gradient of the residual path).
 template <bool REV>
-__global__ __launch_bounds__(256) void half_transpose_kernel(const float* __restrict__ src, float* __restrict__ dst,
-                                                             const float* __restrict__ add, int P, int C, int C2) {
+__device__ __forceinline__ void half_transpose_body(int vblk, const float* __restrict__ src, float* __restrict__ dst,
+                                                    const float* __restrict__ add, int P, int C, int C2) {
   __shared__ float tile[32][33];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const int nbp = (P + 31) / 32, nbi = (C2 + 31) / 32;
-  const int p0 = (blockIdx.x % nbp) * 32, i0 = ((blockIdx.x / nbp) % nbi) * 32, b = blockIdx.x / (nbp * nbi);
+  const int p0 = (vblk % nbp) * 32, i0 = ((vblk / nbp) % nbi) * 32, b = vblk / (nbp * nbi);
   if constexpr (!REV) {
     const float* s = src + (int64_t)b * P * C;
 #pragma unroll
@@ -1397,6 +1399,27 @@ __global__ __launch_bounds__(256) void half_transpose_kernel(const float* __rest
   }
 }
 
+// blocks [0, nT): NHWC left half -> NCHW (optionally with the folded BatchNorm affine); blocks [nT, grid): ln_1 of the right half
+template <int TPR>
+__global__ __launch_bounds__(256) void block_split_fwd_kernel(int nT, const float* __restrict__ inp, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, float eps,
+                                                              const float* __restrict__ left_affine, float* __restrict__ left_nchw,
+                                                              float* __restrict__ rn, float* __restrict__ mu, float* __restrict__ rstd,
+                                                              int64_t nrows, int P, int C, int C2) {
+  if ((int)blockIdx.x < nT) half_transpose_body<false>(blockIdx.x, inp, left_nchw, left_affine, P, C, C2);
+  else ln_half_fwd_body<TPR>(blockIdx.x - nT, gridDim.x - nT, inp, gamma, beta, eps, rn, mu, rstd, nrows, C, C2);
+}
+// blocks [0, nT): d(left) NCHW -> d(inp)[..., :C2] (+ residual gradient); blocks [nT, grid): LayerNorm backward into d(inp)[..., C2:]
+template <int TPR>
+__global__ __launch_bounds__(256) void block_split_bwd_kernel(int nT, const float* __restrict__ dleft_nchw, const float* __restrict__ drn,
+                                                              const float* __restrict__ dres, const float* __restrict__ inp,
+                                                              const float* __restrict__ gamma, const float* __restrict__ mu,
+                                                              const float* __restrict__ rstd, float* __restrict__ dinp,
+                                                              float* __restrict__ ws, int64_t nrows, int P, int C, int C2) {
+  if ((int)blockIdx.x < nT) half_transpose_body<true>(blockIdx.x, dleft_nchw, dinp, dres, P, C, C2);
+  else ln_half_bwd_body<TPR>(blockIdx.x - nT, gridDim.x - nT, drn, inp, gamma, mu, rstd, dres, dinp, ws, nrows, C, C2);
+}
+
 inline int ln_half_grid(int64_t nrows, int tpr) {
   const int64_t waves = (nrows + (64 / tpr) - 1) / (64 / tpr);
   int64_t blocks = (waves + 3) / 4;
@@ -1419,9 +1442,9 @@ int mm_block_split_fwd(const float* inp, const float* gamma, const float* beta, 
   hipStream_t s = (hipStream_t)stream;
   const int C = 2 * C2;
   const int64_t nrows = (int64_t)batch * P;
-  hipLaunchKernelGGL(half_transpose_kernel<false>, dim3(((P + 31) / 32) * ((C2 + 31) / 32) * batch), dim3(256), 0, s, inp, left_nchw, left_affine, P, C, C2);
-  if (C2 <= 128) hipLaunchKernelGGL(ln_half_fwd_kernel<16>, dim3(ln_half_grid(nrows, 16)), dim3(256), 0, s, inp, gamma, beta, eps, rn, mu, rstd, nrows, C, C2);
-  else hipLaunchKernelGGL(ln_half_fwd_kernel<64>, dim3(ln_half_grid(nrows, 64)), dim3(256), 0, s, inp, gamma, beta, eps, rn, mu, rstd, nrows, C, C2);
+  const int nT = ((P + 31) / 32) * ((C2 + 31) / 32) * batch;
+  if (C2 <= 128) hipLaunchKernelGGL(block_split_fwd_kernel<16>, dim3(nT + ln_half_grid(nrows, 16)), dim3(256), 0, s, nT, inp, gamma, beta, eps, left_affine, left_nchw, rn, mu, rstd, nrows, P, C, C2);
+  else hipLaunchKernelGGL(block_split_fwd_kernel<64>, dim3(nT + ln_half_grid(nrows, 64)), dim3(256), 0, s, nT, inp, gamma, beta, eps, left_affine, left_nchw, rn, mu, rstd, nrows, P, C, C2);
   return (int)hipGetLastError();
 }
 
@@ -1433,9 +1456,9 @@ int mm_block_split_bwd(const float* dleft_nchw, const float* drn, const float* d
   hipStream_t s = (hipStream_t)stream;
   const int C = 2 * C2;
   const int64_t nrows = (int64_t)batch * P;
-  hipLaunchKernelGGL(half_transpose_kernel<true>, dim3(((P + 31) / 32) * ((C2 + 31) / 32) * batch), dim3(256), 0, s, dleft_nchw, dinp, dres, P, C, C2);
-  if (C2 <= 128) hipLaunchKernelGGL(ln_half_bwd_kernel<16>, dim3(ln_half_grid(nrows, 16)), dim3(256), 8 * C2 * sizeof(float), s, drn, inp, gamma, mu, rstd, dres, dinp, ws, nrows, C, C2);
-  else hipLaunchKernelGGL(ln_half_bwd_kernel<64>, dim3(ln_half_grid(nrows, 64)), dim3(256), 8 * C2 * sizeof(float), s, drn, inp, gamma, mu, rstd, dres, dinp, ws, nrows, C, C2);
+  const int nT = ((P + 31) / 32) * ((C2 + 31) / 32) * batch;
+  if (C2 <= 128) hipLaunchKernelGGL(block_split_bwd_kernel<16>, dim3(nT + ln_half_grid(nrows, 16)), dim3(256), 8 * C2 * sizeof(float), s, nT, dleft_nchw, drn, dres, inp, gamma, mu, rstd, dinp, ws, nrows, P, C, C2);
+  else hipLaunchKernelGGL(block_split_bwd_kernel<64>, dim3(nT + ln_half_grid(nrows, 64)), dim3(256), 8 * C2 * sizeof(float), s, nT, dleft_nchw, drn, dres, inp, gamma, mu, rstd, dinp, ws, nrows, P, C, C2);
   return (int)hipGetLastError();
 }
 
