@@ -292,7 +292,7 @@ __global__ __launch_bounds__(256) void conv3x3_v2_kernel(const Conv2Params p) {
         float v = xr[ci][i];
         if (p.aff != nullptr) {
           v = fmaf(v, sc, sh);
-          if (p.relu & 1) v = fmaxf(v, 0.f);
+          if (p.relu) v = fmaxf(v, 0.f);
           v = (cok && sl_glb[i] != kOOB) ? v : 0.f;     // the padding is zero AFTER the affine (it pads the BatchNorm's output)
         }
         // slots beyond the patch go to a scratch word behind it instead of branching around the store
@@ -313,27 +313,13 @@ __global__ __launch_bounds__(256) void conv3x3_v2_kernel(const Conv2Params p) {
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 
-  const bool dbg_noload = p.relu & 2, dbg_nomfma = p.relu & 4;      // timing-only ablations (results are wrong when set)
-  if (dbg_noload) {
-#pragma unroll
-    for (int ci = 0; ci < V2_CK; ++ci)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) xr[ci][i] = 0.f;
-#pragma unroll
-    for (int i = 0; i < 5; ++i) wr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-  } else {
-#pragma unroll
-    for (int ci = 0; ci < V2_CK; ++ci)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) xr[ci][i] = 0.f;
-  }
-  if (nchunks > 0 && !dbg_noload) load_chunk(c_begin);
+  if (nchunks > 0) load_chunk(c_begin);
   const int nch_max = (((p.C + 15) / 16) * 8 + V2_CK - 1) / V2_CK;      // both halves run the same number of barriers
   for (int ch = 0; ch < nch_max; ++ch) {
     if (ch < nchunks) store_chunk(c_begin + ch * V2_CK);
     __syncthreads();
-    if (ch + 1 < nchunks && !dbg_noload) load_chunk(c_begin + (ch + 1) * V2_CK);
-    if (ch < nchunks && !dbg_nomfma) {
+    if (ch + 1 < nchunks) load_chunk(c_begin + (ch + 1) * V2_CK);
+    if (ch < nchunks) {
       // operands of the NEXT channel pair (9 taps: 9 A + 9 B registers) are read from LDS while the 9 MFMAs of the current one
       // run — left to itself the compiler emits read, s_waitcnt lgkmcnt(0), mfma per step and the matrix pipe idles for every
       // LDS round trip (measured: 32 % of the MFMA rate)

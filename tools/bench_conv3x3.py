@@ -53,10 +53,8 @@ def main():
         stats2 = torch.empty(lib.mm_conv3x3_v2_tiles(B, HW, HW), C, 3, device=dev)
         t_v2 = timeit(lambda: lib.mm_conv3x3_v2_fwd(x.data_ptr(), wt.data_ptr(), b.data_ptr(), None, 0, y.data_ptr(), stats2.data_ptr(),
                                                     B, C, C, HW, HW, st))
-        abl = [timeit(lambda: lib.mm_conv3x3_v2_fwd(x.data_ptr(), wt.data_ptr(), b.data_ptr(), None, d, y.data_ptr(), stats2.data_ptr(),
-                                                     B, C, C, HW, HW, st)) for d in (2, 4, 6)]
         flop = 2.0 * B * HW * HW * C * C * 9
-        print(f"{B}x{C}x{HW}x{HW:<12} {t_mi:>20.1f} {t_bn:>20.1f} {t_ap:>17.1f} {t_own:>23.1f} {flop / t_own / 1e6:>12.1f}   v2: {t_v2:7.1f} us {flop / t_v2 / 1e6:6.1f} TFLOP/s  [no loads {abl[0]:.1f}, no mfma {abl[1]:.1f}, neither {abl[2]:.1f}]")
+        print(f"{B}x{C}x{HW}x{HW:<12} {t_mi:>20.1f} {t_bn:>20.1f} {t_ap:>17.1f} {t_own:>23.1f} {flop / t_own / 1e6:>12.1f}   v2: {t_v2:7.1f} us {flop / t_v2 / 1e6:6.1f} TFLOP/s")
 
 
 if __name__ == "__main__":
