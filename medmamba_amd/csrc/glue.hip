@@ -1498,39 +1498,55 @@ struct PackExtra {
   const float* dw_ws;      // (batch, D*S, 10) or nullptr
   float* ln_out;           // 2*D: dgamma | dbeta
   float* dw_out;           // D*9 (weight gradient, (D,1,3,3) order) | D (bias gradient)
-  int ln_rows, dw_batch, dw_S, blk_ln, blk_dw;    // blocks [blk_ln, blk_dw) reduce ln_ws, [blk_dw, grid) reduce dw_ws
+  int ln_rows, ln_rl, dw_batch, dw_S, blk_ln, blk_dw;    // blocks [blk_ln, blk_dw) reduce ln_ws, [blk_dw, grid) reduce dw_ws
 };
 
 __device__ __forceinline__ void pack_extra_blocks(const PackExtra& ex, int D, float* red) {
   const int b = blockIdx.x;
   if (b < ex.blk_dw) {
-    // ln: block = 64 columns x 4 row lanes; rows strided by 4, then 4 -> 1 through LDS (fixed order)
-    const int col = (b - ex.blk_ln) * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+    // ln: block = (256 / RL) columns x RL row lanes (RL = ex.ln_rl: 4 for a few hundred rows, 32 for the 3136 rows of the long-
+    // sequence stages, where 4 lanes walked 784 rows each: 90 us); rows strided by RL, then RL -> 1 through LDS in lane order
+    const int RL = ex.ln_rl, COLS = 256 / RL;
+    const int col = (b - ex.blk_ln) * COLS + (int)(threadIdx.x % COLS), rl = threadIdx.x / COLS;
     float a0 = 0.f, a1 = 0.f;
     if (col < 2 * D) {
       const float* src = ex.ln_ws + col;
       int r = rl;
-      for (; r + 4 < ex.ln_rows; r += 8) { a0 += src[(int64_t)r * 2 * D]; a1 += src[(int64_t)(r + 4) * 2 * D]; }
+      for (; r + RL < ex.ln_rows; r += 2 * RL) { a0 += src[(int64_t)r * 2 * D]; a1 += src[(int64_t)(r + RL) * 2 * D]; }
       if (r < ex.ln_rows) a0 += src[(int64_t)r * 2 * D];
     }
     red[threadIdx.x] = a0 + a1;
     __syncthreads();
-    if (rl == 0 && col < 2 * D) ex.ln_out[col] = (red[threadIdx.x] + red[threadIdx.x + 64]) + (red[threadIdx.x + 128] + red[threadIdx.x + 192]);
+    if (rl == 0 && col < 2 * D) {
+      float t = red[threadIdx.x];
+      for (int k = 1; k < RL; ++k) t += red[threadIdx.x + k * COLS];
+      ex.ln_out[col] = t;
+    }
   } else {
-    // depthwise conv: thread = (channel d, j of 10); sums over batch and strips in a fixed order
-    const int o = (b - ex.blk_dw) * 256 + threadIdx.x;
+    // depthwise conv: 4 lanes per output (channel d, j of 10), each a quarter of the batch with 4 loads in flight, joined by DPP
+    // in lane order; sums over batch and strips in a fixed order
+    const int o = (b - ex.blk_dw) * 64 + (int)(threadIdx.x >> 2), part = threadIdx.x & 3;
+    float acc = 0.f;
+    int d = 0, j = 0;
     if (o < D * 10) {
-      const int d = o / 10, j = o - d * 10;
+      d = o / 10; j = o - d * 10;
       const int64_t bstride = (int64_t)D * ex.dw_S * 10;
-      float a0 = 0.f, a1 = 0.f;
+      const int q0 = (ex.dw_batch * part) >> 2, q1 = (ex.dw_batch * (part + 1)) >> 2;
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
       for (int s = 0; s < ex.dw_S; ++s) {
         const float* src = ex.dw_ws + ((int64_t)d * ex.dw_S + s) * 10 + j;
-        int q = 0;
-        for (; q + 1 < ex.dw_batch; q += 2) { a0 += src[q * bstride]; a1 += src[(q + 1) * bstride]; }
-        if (q < ex.dw_batch) a0 += src[q * bstride];
+        int q = q0;
+        for (; q + 3 < q1; q += 4) {
+          a0 += src[q * bstride]; a1 += src[(q + 1) * bstride]; a2 += src[(q + 2) * bstride]; a3 += src[(q + 3) * bstride];
+        }
+        for (; q < q1; ++q) a0 += src[q * bstride];
       }
-      const float v = a0 + a1;
-      if (j < 9) ex.dw_out[d * 9 + j] = v; else ex.dw_out[D * 9 + d] = v;
+      acc = (a0 + a1) + (a2 + a3);
+    }
+    acc += mm::dpp_f<mm::DPP_QUAD_XOR1>(acc);
+    acc += mm::dpp_f<mm::DPP_QUAD_XOR2>(acc);
+    if (part == 0 && o < D * 10) {
+      if (j < 9) ex.dw_out[d * 9 + j] = acc; else ex.dw_out[D * 9 + d] = acc;
     }
   }
 }
@@ -1633,8 +1649,9 @@ int mm_ss2d_pack_bwd(const float* dpacked, const float* packed, const float* par
   ex.ln_ws = ln_ws; ex.ln_rows = ln_rows; ex.ln_out = ln_out;
   ex.dw_ws = dw_ws; ex.dw_batch = dw_batch; ex.dw_S = dw_strips; ex.dw_out = dw_out;
   ex.blk_ln = pg.blk_off[5];
-  ex.blk_dw = ex.blk_ln + (ln_ws ? (2 * D + 63) / 64 : 0);
-  const int grid = ex.blk_dw + (dw_ws ? (D * 10 + 255) / 256 : 0);
+  ex.ln_rl = ln_rows > 1024 ? 32 : (ln_rows > 256 ? 16 : 4);
+  ex.blk_dw = ex.blk_ln + (ln_ws ? (2 * D + 256 / ex.ln_rl - 1) / (256 / ex.ln_rl) : 0);
+  const int grid = ex.blk_dw + (dw_ws ? (D * 10 + 63) / 64 : 0);
   hipLaunchKernelGGL(ss2d_pack_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, dpacked, packed, parts,
                      nullptr, nullptr, grads, D, C, R, N, pg, nparts, ex);
   return (int)hipGetLastError();
