@@ -42,6 +42,7 @@ _OWN_BN = __import__("os").environ.get("MM_OWN_BN", "1") == "1"         # MM_OWN
 # (forward and backward one launch each) — the stages where the step is bound by the host's launch rate.  0 = off.
 _GRAPH_BLOCK_MAX_L = int(__import__("os").environ.get("MM_GRAPH_BLOCK_MAX_L", "0"))
 _SIDE_STREAMS = {}
+_CONV_WARM = set()      # conv-branch input shapes whose MIOpen solver search has run (SS_Conv_SSM.forward)
 # images with at least this many positions start the side stream when the scan kernel is queued (see SS_Conv_SSM.forward)
 _LATE_SIDE_MIN_L = int(__import__("os").environ.get("MM_LATE_SIDE_MIN_L", "2048"))
 
@@ -473,7 +474,8 @@ class SS_Conv_SSM(nn.Module):
             return PointwiseConvFn.apply(t, conv[7].weight, None)                 # pre-activation of the trailing ReLU, without
                                                                                   # the bias (shuffle_residual adds it)
 
-        if _TWO_STREAMS:
+        warm_key = (tuple(left.shape), left.device, "infer")      # see forward(): MIOpen's solver search runs on an idle GPU
+        if _TWO_STREAMS and warm_key in _CONV_WARM:
             main = torch.cuda.current_stream()
             side = _side_stream(input.device)
             left.record_stream(side)
@@ -486,6 +488,7 @@ class SS_Conv_SSM(nn.Module):
         else:
             x_cf = self.self_attention.forward_cf(right_n)
             left = conv_body(left)
+            _CONV_WARM.add(warm_key)
         return shuffle_residual(left, x_cf, input, channel_first=True, ssm_scale=None, left_relu=True, left_bias=conv[7].bias)
 
     def _graphed_conv_body(self, mods, left):
@@ -544,7 +547,13 @@ class SS_Conv_SSM(nn.Module):
         conv_body = lambda t: _conv_branch(mods, t, skip_last_bias=defer_bias)
         if graph_conv:
             conv_body = self._graphed_conv_body(mods, left)
-        if _TWO_STREAMS and input.is_cuda:
+        # PyTorch asks MIOpen to FIND a solver at the first call of every conv configuration, and MIOpen answers by timing its
+        # candidates on the spot.  With the scan running beside them the timings are noise (stage-3 convs landed on an implicit
+        # GEMM + 2 layout transposes instead of Winograd on one box in three): the first pass over a shape — forward and, in
+        # training, the backward that follows it — therefore runs the block on ONE stream, the overlap starts with the next.
+        warm_key = (tuple(left.shape), left.device, torch.is_grad_enabled())
+        cold = input.is_cuda and warm_key not in _CONV_WARM
+        if _TWO_STREAMS and input.is_cuda and not cold:
             # the conv branch and the SS2D branch are independent (MedMamba.py:351-353): run the conv branch on a side
             # HIP stream so that its MIOpen kernels overlap the scan (autograd replays the backward on the same streams)
             main = torch.cuda.current_stream()
@@ -570,6 +579,11 @@ class SS_Conv_SSM(nn.Module):
         else:
             x_cf = self.self_attention.forward_cf(right_n)                                   # (B, C/2, H*W)
             left = conv_body(left)                                                           # stays NCHW
+            if cold:
+                if left.requires_grad:       # every forward of the first step precedes its first backward: warm from then on
+                    left.register_hook(lambda g, k=warm_key: _CONV_WARM.add(k))
+                else:
+                    _CONV_WARM.add(warm_key)
         # trailing ReLU + drop_path + permute back + cat + channel_shuffle(groups=2) + residual (MedMamba.py:347, 353-357)
         # fused in one HIP kernel
         scale = getattr(self, "_dp_factor", None)      # drawn for all blocks at once by VSSM.forward_backbone
