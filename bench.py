@@ -191,8 +191,14 @@ def main():
     model = wrap_ddp(net, dev) if use_torch_ddp else net
     sync = GradSync(net) if (world > 1 and not use_torch_ddp) else None
     # train.py:189-192 (ImageFolder branch); fused=True: same update rule, one multi-tensor kernel per step
-    okw = {"fused": True} if os.environ.get("MM_FUSED_ADAMW", "1") == "1" else {}      # else: torch's default (foreach)
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=1e-4, **okw)
+    # MM_FUSED_ADAMW=1 (default): optim.FusedAdamW = torch.optim.AdamW(fused=True) with its per-step tensor lists cached;
+    # =torch: torch.optim.AdamW(fused=True) itself; =0: torch's default (foreach) implementation
+    fa = os.environ.get("MM_FUSED_ADAMW", "1")
+    if fa == "1":
+        from medmamba_amd.optim import FusedAdamW
+        opt = FusedAdamW(model.parameters(), lr=1e-4, weight_decay=1e-4)
+    else:
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=1e-4, **({"fused": True} if fa == "torch" else {}))
     loss_fn = nn.CrossEntropyLoss()
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     images = torch.randn(args.batch, 3, args.res, args.res, device=dev, generator=g)   # resident in HBM

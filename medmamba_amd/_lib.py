@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "lib", "libmedmamba_hip.so")
 
-ABI_VERSION = 19        # == MM_ABI_VERSION of include/medmamba_hip.h (checked when the library is loaded)
+ABI_VERSION = 20        # == MM_ABI_VERSION of include/medmamba_hip.h (checked when the library is loaded)
 _f32p = ctypes.c_void_p
 _i64 = ctypes.c_int64
 
@@ -98,6 +98,13 @@ SYMBOLS = {
     "mm_ss2d_pack_bwd": (ctypes.c_int, [_f32p] * 4 + [ctypes.c_int] * 5 + [_f32p, ctypes.c_int, _f32p, _f32p, ctypes.c_int, ctypes.c_int,
                                                                               _f32p, ctypes.c_void_p]),
     "mm_ss2d_pack_parts_size": (ctypes.c_int, [ctypes.c_int] * 4),
+    "mm_blas_attach": (ctypes.c_int, [ctypes.c_char_p]),
+    "mm_blas_attached": (ctypes.c_int, []),
+    "mm_blas_set_atomics": (ctypes.c_int, [ctypes.c_int]),
+    "mm_blas_last_status": (ctypes.c_int, []),
+    "mm_gemm_f32": (ctypes.c_int, [ctypes.c_char, ctypes.c_char, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, _f32p, ctypes.c_int,
+                                   _i64, _f32p, ctypes.c_int, _i64, ctypes.c_float, _f32p, ctypes.c_int, _i64, ctypes.c_int, ctypes.c_int32,
+                                   ctypes.c_void_p]),
 }
 
 _lib = None

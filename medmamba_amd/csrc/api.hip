@@ -60,6 +60,7 @@ const char* mm_status_string(int s) {
     case MM_ERR_UNSUPPORTED: return "unsupported variant";
     case MM_ERR_ALIGN: return "misaligned pointer";
     case MM_ERR_WORKSPACE: return "workspace missing";
+    case MM_ERR_BLAS: return "BLAS not attached or BLAS error";
     default: return s > 0 ? hipGetErrorString((hipError_t)s) : "unknown status";
   }
 }

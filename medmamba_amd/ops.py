@@ -3,11 +3,29 @@ import os
 
 import torch
 
-from . import _lib
+from . import _lib, blas
 
 
 def _stream():
     return _lib.raw_stream()
+
+
+def _gemm(a, b, out=None, batch=None):
+    """a @ b as ONE fp32 GEMM launch: a (m, k) or (B, m, k), b (k, n) or (B, k, n); a 2-D operand of a 3-D product is shared by
+    the batch.  rocBLAS directly when a solution is recorded for the shape (blas.gemm: 7.6 us of host time instead of 17-31 us
+    through the dispatcher), torch.mm / torch.bmm otherwise.  `out` must be fully overwritable (uninitialised is fine)."""
+    three = a.dim() == 3 or b.dim() == 3
+    if out is None:
+        nb = a.shape[0] if a.dim() == 3 else (b.shape[0] if b.dim() == 3 else 0)
+        out = torch.empty(((nb,) if three else ()) + (a.shape[-2], b.shape[-1]), device=a.device, dtype=torch.float32)
+    if not blas.gemm(out, a, b):
+        if three:
+            nb = out.shape[0]
+            torch.bmm(a if a.dim() == 3 else a.unsqueeze(0).expand(nb, -1, -1), b if b.dim() == 3 else b.unsqueeze(0).expand(nb, -1, -1),
+                      out=out)
+        else:
+            torch.mm(a, b, out=out)
+    return out
 
 
 def _need_hip(*ts):
@@ -150,12 +168,12 @@ class InProjFn(torch.autograd.Function):
         cm = channel_major(Bsz, L)
         if cm:
             x = x.contiguous()
-            xz = torch.mm(weight, x.view(Bsz * L, dm).t())                                    # (2D, B*L)
+            xz = _gemm(weight, x.view(Bsz * L, dm).t())                                       # (2D, B*L)
             if bias is not None:
                 xz += bias[:, None]
             xz = xz.view(2 * D, Bsz, L).permute(1, 0, 2)
         else:
-            xz = torch.bmm(weight.unsqueeze(0).expand(Bsz, -1, -1), x.transpose(1, 2))          # (B, 2D, L)
+            xz = _gemm(weight, x.transpose(1, 2))                                             # (B, 2D, L)
             if bias is not None:
                 xz += bias[:, None]
         ctx.save_for_backward(x, weight)
@@ -174,11 +192,11 @@ class InProjFn(torch.autograd.Function):
         if g is not None:              # the SS2D core hands both gradients back as halves of one (B, 2D, L) buffer
             if ctx.cm and _is_cm(g):
                 g2, x2 = _cm2d(g), x.view(Bsz * L, dm)
-                dx = torch.mm(g2.t(), weight).view(Bsz, L, dm)
-                torch.mm(g2, x2, out=dw)
+                dx = _gemm(g2.t(), weight).view(Bsz, L, dm)
+                _gemm(g2, x2, out=dw)
             else:
-                dx = torch.bmm(g.transpose(1, 2), weight.unsqueeze(0).expand(Bsz, -1, -1))
-                torch.sum(torch.bmm(g, x), dim=0, out=dw)
+                dx = _gemm(g.transpose(1, 2), weight)
+                torch.sum(_gemm(g, x), dim=0, out=dw)
         elif ctx.cm:
             gx, gz, x2 = _cm2d(dx_cf), _cm2d(dz_cf), x.view(Bsz * L, dm)                         # (D, B*L) each
             dx = torch.mm(gx.t(), w0)
@@ -203,16 +221,44 @@ def in_proj_cf(x_rows, weight, bias):
     return InProjFn.apply(x_rows, weight, bias)
 
 
+class OutProjFn(torch.autograd.Function):
+    """SS2D.out_proj without bias (MedMamba.py:302) on channel-first planes, one GEMM launch per product: over B*L columns for
+    channel-major planes, batched over B otherwise (the weight gradient then takes a sum over B)."""
+
+    @staticmethod
+    def forward(ctx, y_cf, weight):
+        B, D, L = y_cf.shape
+        cm = B > 1 and _is_cm(y_cf)
+        ctx.save_for_backward(y_cf, weight)
+        ctx.cm = cm
+        if cm:
+            return _gemm(weight, _cm2d(y_cf)).view(-1, B, L).permute(1, 0, 2)
+        y_cf = _rows(y_cf)
+        return _gemm(weight, y_cf)
+
+    @staticmethod
+    def backward(ctx, dout):
+        y_cf, weight = ctx.saved_tensors
+        B, D, L = y_cf.shape
+        dy = dw = None
+        if ctx.cm and B > 1 and _is_cm(dout):
+            g2 = _cm2d(dout)                                                                   # (d_model, B*L)
+            if ctx.needs_input_grad[0]:
+                dy = _gemm(weight.t(), g2).view(D, B, L).permute(1, 0, 2)
+            if ctx.needs_input_grad[1]:
+                dw = _gemm(g2, _cm2d(y_cf).t())
+        else:
+            g = _rows(dout)
+            if ctx.needs_input_grad[0]:
+                dy = _gemm(weight.t(), g)
+            if ctx.needs_input_grad[1]:
+                dw = _gemm(g, _rows(y_cf).transpose(1, 2)).sum(0)
+        return dy, dw
+
+
 def out_proj_cf(y_cf, weight, bias=None):
-    """SS2D.out_proj (MedMamba.py:302) on channel-first planes: (B, D, L) -> (B, d_model, L) in the storage layout of y_cf
-    (plain autograd ops: one GEMM over B*L columns for channel-major planes, a batched GEMM otherwise)."""
-    B, D, L = y_cf.shape
-    if B > 1 and _is_cm(y_cf):
-        out = torch.mm(weight, y_cf.permute(1, 0, 2).reshape(D, B * L))
-        if bias is not None:
-            out = out + bias[:, None]
-        return out.view(-1, B, L).permute(1, 0, 2)
-    out = torch.bmm(weight.unsqueeze(0).expand(B, -1, -1), y_cf)
+    """SS2D.out_proj (MedMamba.py:302) on channel-first planes: (B, D, L) -> (B, d_model, L) in the storage layout of y_cf."""
+    out = OutProjFn.apply(y_cf, weight)
     return out if bias is None else out + bias[:, None]
 
 
@@ -325,7 +371,7 @@ class SS2DCoreFn(torch.autograd.Function):
         if cm:
             u2m = _cm2d(_rows(u2))                                                             # (2D, Q)
             u2 = u2m.view(2 * D, Bsz, L).permute(1, 0, 2)
-            x_dbl = torch.bmm(Wx.view(2, 2 * C, D), u2m.view(2, D, Q)).view(4, C, Q)              # :259
+            x_dbl = _gemm(Wx.view(2, 2 * C, D), u2m.view(2, D, Q)).view(4, C, Q)                  # :259
             xb = x_dbl.view(4, C, Bsz, L).permute(2, 0, 1, 3)                                   # (B, 4, C, L) view
         else:
             u2 = u2.float().contiguous()
@@ -338,7 +384,7 @@ class SS2DCoreFn(torch.autograd.Function):
         if fuse_dt:
             delta = None
         elif cm:
-            delta = torch.bmm(Wdt, x_dbl[:, :R]).view(4 * D, Bsz, L).permute(1, 0, 2)            # :262  (B, 4D, L) view
+            delta = _gemm(Wdt, x_dbl[:, :R]).view(4 * D, Bsz, L).permute(1, 0, 2)                # :262  (B, 4D, L) view
         else:
             delta = torch.matmul(Wdt.unsqueeze(0), x_dbl[:, :, :R]).view(Bsz, 4 * D, L)
         if prescan_event is not None:
@@ -409,16 +455,16 @@ class SS2DCoreFn(torch.autograd.Function):
                                   parts=(parts, 0, dD.storage_offset() - oA, ddb.storage_offset() - oA), channel_major=cm)[:2]
         if cm:
             dd = ddelta.permute(1, 0, 2).reshape(4, D, Q)                                      # views of (4D, B, L) storage
-            torch.bmm(dd, x_dbl[:, :R].transpose(1, 2), out=dWdt)                               # (4, D, R)
-            torch.bmm(Wdt.transpose(1, 2), dd, out=dx_dbl[:, :R])                               # dt rows of d(x_dbl), in place
+            _gemm(dd, x_dbl[:, :R].transpose(1, 2), out=dWdt)                                   # (4, D, R)
+            _gemm(Wdt.transpose(1, 2), dd, out=dx_dbl[:, :R])                                   # dt rows of d(x_dbl), in place
             dx2 = dx_dbl.view(2, 2 * C, Q)
             if fused_conv:
-                du2m = torch.bmm(Wx.view(2, 2 * C, D).transpose(1, 2), dx2)                      # Wx^T d(x_dbl); pairs added later
+                du2m = _gemm(Wx.view(2, 2 * C, D).transpose(1, 2), dx2)                          # Wx^T d(x_dbl); pairs added later
             else:
                 d4 = du4.permute(1, 0, 2).reshape(2, 2, D, Q)
                 du2m = d4[:, 0] + d4[:, 1]                                                     # the two directions of a pair
                 du2m.baddbmm_(Wx.view(2, 2 * C, D).transpose(1, 2), dx2)                         # + Wx^T d(x_dbl)
-            torch.bmm(dx2, _cm2d(u2).view(2, D, Q).transpose(1, 2), out=dWx.view(2, 2 * C, D))
+            _gemm(dx2, _cm2d(u2).view(2, D, Q).transpose(1, 2), out=dWx.view(2, 2 * C, D))
             du2 = du2m.view(2 * D, Bsz, L).permute(1, 0, 2)
         else:
             dd = ddelta.view(Bsz, 4, D, L)
@@ -573,8 +619,7 @@ class PointwiseConvFn(torch.autograd.Function):
         B, C, H, W = x.shape
         w = weight.view(weight.shape[0], C)
         x3 = x.reshape(B, C, H * W)
-        wb = w.unsqueeze(0).expand(B, -1, -1)
-        out = torch.bmm(wb, x3) if bias is None else torch.baddbmm(bias.view(1, -1, 1), wb, x3)
+        out = _gemm(w, x3) if bias is None else torch.baddbmm(bias.view(1, -1, 1), w.unsqueeze(0).expand(B, -1, -1), x3)
         ctx.save_for_backward(x3, w)
         ctx.shape = (B, C, H, W, bias is not None, weight.shape)
         return out.view(B, -1, H, W)
@@ -584,8 +629,8 @@ class PointwiseConvFn(torch.autograd.Function):
         x3, w = ctx.saved_tensors
         B, C, H, W, has_bias, wshape = ctx.shape
         dy3 = dy.contiguous().view(B, -1, H * W)
-        dx = torch.bmm(w.t().unsqueeze(0).expand(B, -1, -1), dy3).view(B, C, H, W) if ctx.needs_input_grad[0] else None
-        dw = torch.bmm(dy3, x3.transpose(1, 2)).sum(0).view(wshape) if ctx.needs_input_grad[1] else None
+        dx = _gemm(w.t(), dy3).view(B, C, H, W) if ctx.needs_input_grad[0] else None
+        dw = _gemm(dy3, x3.transpose(1, 2)).sum(0).view(wshape) if ctx.needs_input_grad[1] else None
         db = _bias_grad(dy3) if (has_bias and ctx.needs_input_grad[2]) else None
         return dx, dw, db
 

@@ -69,11 +69,14 @@ def make_optimizer(net, is_npz, lr, lr_decay_epochs, fused=None):
     params = list(net.parameters())
     if fused is None:
         fused = bool(params) and params[0].is_cuda
-    kw = {"fused": True} if fused else {}
-    if is_npz:
-        opt = torch.optim.AdamW(params, lr=lr, **kw)
+    if fused:                     # same optimizer and state, per-step Python bookkeeping cached (optim.FusedAdamW)
+        from .optim import FusedAdamW as AdamW
     else:
-        opt = torch.optim.AdamW(params, lr=lr, betas=(0.9, 0.999), weight_decay=1e-4, **kw)
+        AdamW = torch.optim.AdamW
+    if is_npz:
+        opt = AdamW(params, lr=lr)
+    else:
+        opt = AdamW(params, lr=lr, betas=(0.9, 0.999), weight_decay=1e-4)
     sched = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=lr_decay_epochs, gamma=0.1) if (is_npz and lr_decay_epochs) else None
     return opt, sched
 

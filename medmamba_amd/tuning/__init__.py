@@ -24,4 +24,6 @@ def enable_tuned_gemms(path=None, tune=False):
     t.enable(True)
     t.tuning_enable(bool(tune))
     t.set_filename(path, insert_device_ordinal=False)
+    from .. import blas
+    blas.load_table(path)          # the same record drives the direct rocBLAS route of the package's own GEMM call sites
     return path

@@ -143,6 +143,24 @@ def test_bad_arguments_are_rejected_without_launch():
         _lib.check(-3, "x")
 
 
+def test_gemm_entry_refuses_without_an_attached_blas():
+    """mm_gemm_f32 links no BLAS of its own: until mm_blas_attach has been given the host process's rocBLAS it returns MM_ERR_BLAS
+    (nothing is launched), and the Python route (medmamba_amd.blas.gemm) declines, so callers keep their torch GEMM."""
+    from medmamba_amd import blas
+    lib = _lib.lib()
+    assert lib.mm_blas_attach(None) == -1
+    assert lib.mm_blas_attach(b"/nonexistent/librocblas.so") == -6
+    if not lib.mm_blas_attached():
+        assert lib.mm_gemm_f32(b"N", b"N", 4, 4, 4, 1.0, 64, 4, 0, 64, 4, 0, 0.0, 64, 4, 0, 1, 0, None) == -6
+    assert lib.mm_status_string(-6).decode().startswith("BLAS")
+    if not torch.cuda.is_available():
+        assert blas.load_table(os.path.join(os.path.dirname(blas.__file__), "tuning", "gemm_gfx950.csv")) == 0
+        a = torch.zeros(4, 4)
+        assert blas.gemm(torch.zeros(4, 4), a, a) is False
+    assert blas._operand(torch.zeros(6, 5)) == ("n", 5) and blas._operand(torch.zeros(5, 6).t()) == ("t", 6)
+    assert blas._operand(torch.zeros(6, 10)[:, ::2]) == (None, 0)
+
+
 def test_operator_has_no_cpu_fallback_and_mirrors_reference_errors():
     u = torch.zeros(1, 8, 8); A = torch.zeros(8, 16); B = torch.zeros(1, 4, 16, 8)
     with pytest.raises(RuntimeError, match="HIP device"):

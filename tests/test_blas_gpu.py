@@ -1,0 +1,124 @@
+"""GPU: the direct rocBLAS route of the projections (medmamba_amd.blas / mm_gemm_f32) against torch's own GEMMs.
+
+blas.any_shape(True) sends every GEMM of the package's call sites through mm_gemm_f32 (unrecorded shapes with rocBLAS's default
+solution), so the small shapes used here exercise the same operand descriptions (transposes, leading dimensions, broadcast
+operands, strided outputs) as the recorded full-size ones."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture
+def direct():
+    from medmamba_amd import blas
+    assert blas.any_shape(True), "rocBLAS of this process could not be attached"
+    blas.STATS["direct"] = 0
+    yield blas
+    blas.any_shape(False)
+
+
+def test_operand_forms_match_torch(direct):
+    blas = direct
+    g = torch.Generator(device=DEV).manual_seed(0)
+    rnd = lambda *s: torch.randn(*s, device=DEV, generator=g)
+    m, n, k, B = 37, 52, 19, 5
+    cases = []
+    for ta in (False, True):
+        for tb in (False, True):
+            a2 = rnd(k, m).t() if ta else rnd(m, k)
+            b2 = rnd(n, k).t() if tb else rnd(k, n)
+            a3 = rnd(B, k, m).transpose(1, 2) if ta else rnd(B, m, k)
+            b3 = rnd(B, n, k).transpose(1, 2) if tb else rnd(B, k, n)
+            cases += [(a2, b2), (a3, b3), (a2, b3), (a3, b2)]
+    for a, b in cases:
+        want = torch.matmul(a, b)
+        out = torch.full_like(want, float("nan"))
+        assert blas.gemm(out, a, b)
+        assert torch.allclose(out, want, rtol=1e-4, atol=1e-4), (a.shape, a.stride(), b.shape, b.stride())
+    # strided output rows (a row block of a wider buffer), operands that are row blocks themselves, beta = 1
+    big = rnd(4, 10, 64)
+    a, b = rnd(4, 3, 7), rnd(4, 7, 64)
+    ref = big.clone()
+    ref[:, 2:5] = torch.bmm(a, b)
+    assert blas.gemm(big[:, 2:5], a, b)
+    assert torch.allclose(big, ref, rtol=1e-4, atol=1e-4)
+    acc = rnd(4, 3, 64)
+    ref = acc + torch.bmm(a, big[:, :7])
+    assert blas.gemm(acc, a, big[:, :7], beta=1.0)
+    assert torch.allclose(acc, ref, rtol=1e-4, atol=1e-4)
+    # a layout rocBLAS cannot take (no unit stride in either matrix dimension) is declined, nothing is written
+    out = torch.zeros(m, n, device=DEV)
+    assert not blas.gemm(out, rnd(m, 2 * k)[:, ::2], rnd(k, n))
+    assert float(out.abs().max()) == 0.0
+    assert blas.STATS["direct"] >= len(cases) + 2
+
+
+@pytest.mark.parametrize("layout", ["bm", "cm"])
+def test_tiny_model_direct_route_matches_torch_route(layout, monkeypatch, capsys):
+    from medmamba_amd import blas, modules, ops
+    torch.manual_seed(5)
+    net = modules.VSSM(num_classes=4, depths=[1, 1, 1, 1], dims=[16, 32, 64, 128], drop_path_rate=0.0).to(DEV).train()
+    x = torch.randn(3, 3, 64, 64, device=DEV)
+    y = torch.randint(0, 4, (3,), device=DEV)
+    monkeypatch.setattr(ops, "_LAYOUT", layout)
+
+    def run():
+        net.zero_grad(set_to_none=True)
+        logits = net(x)
+        torch.nn.functional.cross_entropy(logits, y).backward()
+        return logits.detach().clone(), {k: p.grad.clone() for k, p in net.named_parameters()}
+
+    l0, g0 = run()
+    assert blas.any_shape(True)
+    blas.STATS["direct"] = 0
+    try:
+        l1, g1 = run()
+    finally:
+        blas.any_shape(False)
+    assert blas.STATS["direct"] >= 4 * (14 if layout == "cm" else 8), blas.STATS     # GEMMs per block that went the direct way
+    assert (l1 - l0).abs().max().item() <= 1e-4 * max(1.0, l0.abs().max().item())
+    for k in g0:
+        scale = max(1e-4, g0[k].abs().max().item())
+        assert (g1[k] - g0[k]).abs().max().item() <= 2e-3 * scale, (layout, k)
+
+
+def test_recorded_solutions_are_used_at_full_size():
+    """The shapes of MedMamba-S at 64 x 224^2 are in the table with the rocBLAS build of this image: one 14x14 block (channel-major
+    planes) sends its projections through the recorded solutions and agrees with the torch route."""
+    from medmamba_amd import blas, modules
+    from medmamba_amd.tuning import enable_tuned_gemms
+    enable_tuned_gemms()
+    if not blas._TABLE:
+        pytest.skip("GEMM table not recorded for this rocBLAS build")
+    try:
+        torch.manual_seed(0)
+        blk = modules.SS_Conv_SSM(hidden_dim=384, drop_path=0.0, norm_layer=torch.nn.LayerNorm).to(DEV).train()
+        x = torch.randn(64, 14, 14, 384, device=DEV, requires_grad=True)
+        g = torch.randn(64, 14, 14, 384, device=DEV)
+
+        def run():
+            blk.zero_grad(set_to_none=True)
+            x.grad = None
+            out = blk(x)
+            out.backward(g)
+            return out.detach().clone(), x.grad.clone(), {k: p.grad.clone() for k, p in blk.named_parameters()}
+
+        blas.STATS["direct"] = 0
+        o1, dx1, g1 = run()
+        n_direct = blas.STATS["direct"]
+        saved = dict(blas._TABLE)
+        blas._TABLE.clear()
+        try:
+            o0, dx0, g0 = run()
+        finally:
+            blas._TABLE.update(saved)
+        assert n_direct >= 10, n_direct
+        assert torch.allclose(o1, o0, rtol=1e-4, atol=1e-4)
+        assert (dx1 - dx0).abs().max().item() <= 2e-3 * dx0.abs().max().item()
+        for k in g0:
+            assert (g1[k] - g0[k]).abs().max().item() <= 2e-3 * max(1e-4, g0[k].abs().max().item()), k
+    finally:
+        torch.cuda.tunable.enable(False)
+        blas._TABLE.clear()

@@ -11,7 +11,11 @@ if os.environ.get("MM_TUNED_GEMMS", "1") == "1":
 dev = torch.device("cuda:0")
 torch.manual_seed(42)
 net = VSSM(num_classes=6, **MEDMAMBA_CONFIGS["S"]).to(dev).train()
-opt = torch.optim.AdamW(net.parameters(), lr=1e-4, weight_decay=1e-4, fused=True)
+if os.environ.get("MM_FUSED_ADAMW", "1") == "1":
+    from medmamba_amd.optim import FusedAdamW
+    opt = FusedAdamW(net.parameters(), lr=1e-4, weight_decay=1e-4)
+else:
+    opt = torch.optim.AdamW(net.parameters(), lr=1e-4, weight_decay=1e-4, fused=True)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 x = torch.randn(B, 3, 224, 224, device=dev); y = torch.randint(0, 6, (B,), device=dev)
 def step():
