@@ -365,6 +365,10 @@ int mm_gemm_f32(char opa, char opb, int m, int n, int k, float alpha, const floa
                 int ldb, int64_t stride_b, float beta, float* C, int ldc, int64_t stride_c, int batch, int32_t solution,
                 void* stream);
 
+/* hipEventRecord(event, stream) for host code that holds no HIP headers (the C++ sequencing layer brackets the scan kernels with
+ * the caller's timing events). */
+int mm_event_record(void* event, void* stream);
+
 int mm_abi_version(void);
 const char* mm_status_string(int status);
 

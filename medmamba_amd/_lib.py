@@ -98,6 +98,7 @@ SYMBOLS = {
     "mm_ss2d_pack_bwd": (ctypes.c_int, [_f32p] * 4 + [ctypes.c_int] * 5 + [_f32p, ctypes.c_int, _f32p, _f32p, ctypes.c_int, ctypes.c_int,
                                                                               _f32p, ctypes.c_void_p]),
     "mm_ss2d_pack_parts_size": (ctypes.c_int, [ctypes.c_int] * 4),
+    "mm_event_record": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "mm_blas_attach": (ctypes.c_int, [ctypes.c_char_p]),
     "mm_blas_attached": (ctypes.c_int, []),
     "mm_blas_set_atomics": (ctypes.c_int, [ctypes.c_int]),

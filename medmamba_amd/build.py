@@ -52,5 +52,35 @@ def build(force=False, verbose=False, extra=()):
     return SO
 
 
+# ---- the C++ sequencing layer (csrc_host/*.cpp): a torch extension without device code, compiled with g++ against torch's
+# headers and linked against the library above (ops.SS2DBranchFn loads it; everything still works without it, from Python)
+HOST_SRC = os.path.join(HERE, "csrc_host")
+HOST_SO = os.path.join(LIBDIR, "_mm_host.so")
+CXX = os.environ.get("CXX", "g++")
+
+
+def build_host(force=False, verbose=False):
+    import sysconfig
+
+    import torch
+    from torch.utils import cpp_extension as ce
+    build(force=False, verbose=verbose)
+    srcs = sorted(os.path.join(HOST_SRC, f) for f in os.listdir(HOST_SRC) if f.endswith(".cpp"))
+    newest = max([os.path.getmtime(f) for f in srcs] + [os.path.getmtime(os.path.join(ROOT, "include", "medmamba_hip.h"))])
+    if not force and os.path.exists(HOST_SO) and os.path.getmtime(HOST_SO) >= newest:
+        return HOST_SO
+    inc = [p for p in ce.include_paths() if os.path.isdir(p)] + [sysconfig.get_paths()["include"], os.path.join(ROOT, "include")]
+    tlib = os.path.join(os.path.dirname(torch.__file__), "lib")
+    cmd = [CXX, "-O2", "-std=c++17", "-fPIC", "-shared", "-DTORCH_EXTENSION_NAME=_mm_host", "-DTORCH_API_INCLUDE_EXTENSION_H",
+           f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}", "-Wall", "-Wno-unused-function",
+           *["-I" + p for p in inc], *srcs, "-o", HOST_SO, "-L" + LIBDIR, "-lmedmamba_hip", "-Wl,-rpath,$ORIGIN",
+           "-L" + tlib, "-ltorch", "-ltorch_cpu", "-lc10", "-ltorch_python", "-Wl,-rpath," + tlib]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return HOST_SO
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_host(force="--force" in sys.argv, verbose=True))

@@ -62,6 +62,11 @@ int mm_blas_attach(const char* path) {
   return MM_OK;
 }
 
+int mm_event_record(void* event, void* stream) {
+  if (!event) return MM_ERR_NULL;
+  return hipEventRecord((hipEvent_t)event, (hipStream_t)stream) == hipSuccess ? MM_OK : MM_ERR_UNSUPPORTED;
+}
+
 int mm_blas_attached(void) { return g_blas.dl != nullptr; }
 
 int mm_blas_set_atomics(int allowed) {

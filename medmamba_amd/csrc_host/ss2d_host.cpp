@@ -1,0 +1,335 @@
+// Host-side sequencing of the SS2D branch (MedMamba.py:288-305) in C++: in_proj -> depthwise conv + SiLU -> x / dt projections
+// -> 4-direction selective scan -> cross-merge -> out_norm + gate -> out_proj, and its backward, each as ONE call from Python.
+//
+// Why this file exists: the kernels are launched through the C ABI (include/medmamba_hip.h) and the GEMMs through ATen either
+// way, but issuing them from Python costs 0.2 ms (forward) + 0.4 ms (backward) of interpreter time per block on top of the
+// launches themselves (tools/host_op_profile.py: SS2DCoreFn / InProjFn / OutProjFn and their backwards), on a training step that
+// is within 10 % of being bound by the host's launch rate.  The sequence below is the one medmamba_amd/ops.py holds
+// (InProjFn, SS2DCoreFn with the fused depthwise conv, OutProjFn) statement by statement — same allocations, same GEMM shapes
+// and strides (hence the same recorded GEMM kernels), same kernels — so both routes give the same bits; ops.py stays as the
+// route for everything this file does not take (biases on the projections, d_state != 16, hooks, inference with the fused dt
+// projection) and as its test oracle on the GPU.
+//
+// No device code and no HIP headers here: the stream is handed over as an integer, device memory as at::Tensor.
+#include <torch/extension.h>
+
+#include <vector>
+
+#include "medmamba_hip.h"
+
+namespace {
+
+using at::Tensor;
+const int64_t kDim0[1] = {0};
+const at::IntArrayRef DIM0(kDim0, 1);
+
+inline void check(int rc, const char* what) {
+  TORCH_CHECK(rc == 0, what, " failed: status ", rc, " (", mm_status_string(rc), ")");
+}
+
+inline const float* fp(const Tensor& t) { return t.defined() ? t.data_ptr<float>() : nullptr; }
+inline float* fpm(const Tensor& t) { return t.defined() ? t.data_ptr<float>() : nullptr; }
+
+inline Tensor planes(int64_t B, int64_t D, int64_t L, const at::TensorOptions& o, bool cm) {
+  return cm ? at::empty({D, B, L}, o).permute({1, 0, 2}) : at::empty({B, D, L}, o);
+}
+
+inline bool is_cm(const Tensor& t) {
+  const int64_t B = t.size(0), L = t.size(2);
+  return t.stride(2) == 1 && t.stride(1) == B * L && (B == 1 || t.stride(0) == L);
+}
+
+// (D, B*L) matrix over the storage of a channel-major (B, D, L) tensor (a copy is made for any other layout)
+inline Tensor cm2d(const Tensor& t_) {
+  Tensor t = t_;
+  const int64_t B = t.size(0), D = t.size(1), L = t.size(2);
+  if (!is_cm(t)) t = t.permute({1, 0, 2}).contiguous().permute({1, 0, 2});
+  return t.permute({1, 0, 2}).reshape({D, B * L});
+}
+
+inline Tensor rows(const Tensor& t) { return t.stride(-1) == 1 ? t : t.contiguous(); }
+
+struct Seg { Tensor Wx, Wdt, A, Dp, bias; int64_t oA, oD, ob; };
+inline Seg segments(const Tensor& P, int64_t D, int64_t C, int64_t R, int64_t N) {
+  auto al = [](int64_t n) { return (n + 63) & ~int64_t(63); };        // segments start on 256-B boundaries (mm_ss2d_pack_fwd)
+  const int64_t o1 = al(4 * C * D), o2 = al(o1 + 4 * D * R), o3 = al(o2 + 4 * D * N), o4 = al(o3 + 4 * D);
+  Seg s;
+  s.Wx = P.narrow(0, 0, 4 * C * D).view({4, C, D});
+  s.Wdt = P.narrow(0, o1, 4 * D * R).view({4, D, R});
+  s.A = P.narrow(0, o2, 4 * D * N).view({4 * D, N});
+  s.Dp = P.narrow(0, o3, 4 * D);
+  s.bias = P.narrow(0, o4, 4 * D);
+  s.oA = o2; s.oD = o3; s.ob = o4;
+  return s;
+}
+
+inline void fill_common(mm_scan_args& a, const Tensor& u, const Tensor& delta, const Tensor& A, const Tensor& Bm, const Tensor& Cm,
+                        const Tensor& Dp, const Tensor& bias) {
+  a.struct_size = sizeof(mm_scan_args);
+  a.batch = (int)u.size(0); a.dim = (int)A.size(0); a.L = (int)u.size(2); a.N = (int)A.size(1); a.G = (int)Bm.size(1);
+  a.delta_softplus = 1;
+  a.u = fp(u); a.delta = fp(delta); a.A = fp(A); a.B = fp(Bm); a.C = fp(Cm); a.D = fp(Dp); a.delta_bias = fp(bias);
+  a.u_sb = u.stride(0); a.u_sd = u.stride(1);
+  a.delta_sb = delta.stride(0); a.delta_sd = delta.stride(1);
+  a.B_sb = Bm.stride(0); a.B_sg = Bm.stride(1); a.B_sn = Bm.stride(2);
+  a.C_sb = Cm.stride(0); a.C_sg = Cm.stride(1); a.C_sn = Cm.stride(2);
+  a.u_groups = 2; a.u_map = 0x1100u; a.rev_mask = 0b1010u;          // SS2D: 2 image orders, 4 directions (selective_scan_interface._CROSS_SHARED)
+}
+
+// uninitialised fp32 (lead, *dst.shape) whose planes have the same dimension order in memory as the view `dst` (dense)
+inline Tensor like_strided(const Tensor& dst, int64_t lead) {
+  const int64_t nd = dst.dim();
+  std::vector<int64_t> order(nd);
+  for (int64_t i = 0; i < nd; ++i) order[i] = i;
+  std::stable_sort(order.begin(), order.end(), [&](int64_t x, int64_t y) { return dst.stride(x) > dst.stride(y); });
+  std::vector<int64_t> shape{lead}, perm(nd + 1);
+  for (int64_t i = 0; i < nd; ++i) shape.push_back(dst.size(order[i]));
+  perm[0] = 0;
+  for (int64_t pos = 0; pos < nd; ++pos) perm[order[pos] + 1] = pos + 1;
+  return at::empty(shape, dst.options()).permute(perm);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// forward.  Returns {out (B, d_model, L), xz, u2, x_dbl, delta, P, x_chk, m, mu, rstd, y}
+// ---------------------------------------------------------------------------------------------------------------------
+std::vector<Tensor> ss2d_fwd(const Tensor& x, const Tensor& in_w, const Tensor& conv_w, const c10::optional<Tensor>& conv_b_,
+                             const Tensor& x_proj_w, const Tensor& dt_w, const Tensor& dt_b, const Tensor& A_logs, const Tensor& Ds,
+                             const Tensor& ln_w, const Tensor& ln_b, const Tensor& out_w, int64_t H, int64_t W, double eps, bool cm,
+                             bool need_grad, int64_t variant, int64_t stream_, int64_t ev0, int64_t ev1, py::object prescan) {
+  void* stream = reinterpret_cast<void*>(stream_);
+  const Tensor conv_b = conv_b_.has_value() ? *conv_b_ : Tensor();
+  const int64_t Bsz = x.size(0), L = x.size(1), dm = x.size(2);
+  const int64_t D = in_w.size(0) / 2, R = dt_w.size(2), N = A_logs.size(1), C = R + 2 * N, Q = Bsz * L;
+  TORCH_CHECK(L == H * W && x.is_contiguous() && in_w.size(1) == dm && N == 16, "ss2d_fwd: unexpected shapes");
+  const auto o = x.options();
+  // in_proj (:291-292): the two channel-first halves x | z of one buffer
+  Tensor xz;
+  if (cm) {
+    xz = at::empty({2 * D, Q}, o);
+    at::mm_out(xz, in_w, x.view({Q, dm}).t());
+    xz = xz.view({2 * D, Bsz, L}).permute({1, 0, 2});
+  } else {
+    xz = at::empty({Bsz, 2 * D, L}, o);
+    at::bmm_out(xz, in_w.unsqueeze(0).expand({Bsz, -1, -1}), x.transpose(1, 2));
+  }
+  const Tensor x_cf = xz.narrow(1, 0, D), z_cf = xz.narrow(1, D, D);
+  // depthwise conv3x3 + SiLU in both image orders (:294-295, :256)
+  Tensor u2 = planes(Bsz, 2 * D, L, o, cm);
+  check(mm_dwconv_silu_cross_fwd(fp(x_cf), x_cf.stride(0), x_cf.stride(1), fp(conv_w), fp(conv_b), fpm(u2), u2.stride(0), u2.stride(1),
+                                 (int)Bsz, (int)D, (int)H, (int)W, stream), "mm_dwconv_silu_cross_fwd");
+  // parameters in kernel direction order, A = -exp(A_logs) (:271)
+  Tensor P = at::empty({mm_ss2d_pack_size((int)D, (int)C, (int)R, (int)N)}, o);
+  check(mm_ss2d_pack_fwd(fp(x_proj_w), fp(dt_w), fp(dt_b), fp(A_logs), fp(Ds), fpm(P), (int)D, (int)C, (int)R, (int)N, stream),
+        "mm_ss2d_pack_fwd");
+  const Seg s = segments(P, D, C, R, N);
+  Tensor x_dbl, xb, delta;
+  if (cm) {
+    const Tensor u2m = cm2d(u2);                                                          // (2D, Q) view
+    x_dbl = at::empty({2, 2 * C, Q}, o);
+    at::bmm_out(x_dbl, s.Wx.view({2, 2 * C, D}), u2m.view({2, D, Q}));                      // :259
+    x_dbl = x_dbl.view({4, C, Q});
+    xb = x_dbl.view({4, C, Bsz, L}).permute({2, 0, 1, 3});                                // (B, 4, C, L) view
+    delta = at::empty({4, D, Q}, o);
+    at::bmm_out(delta, s.Wdt, x_dbl.narrow(1, 0, R));                                     // :262
+    delta = delta.view({4 * D, Bsz, L}).permute({1, 0, 2});
+  } else {
+    x_dbl = at::matmul(s.Wx.view({1, 2, 2 * C, D}), u2.view({Bsz, 2, D, L})).view({Bsz, 4, C, L});
+    xb = x_dbl;
+    delta = at::matmul(s.Wdt.unsqueeze(0), x_dbl.narrow(2, 0, R)).view({Bsz, 4 * D, L});
+  }
+  if (!prescan.is_none()) prescan.attr("record")();       // the projections are queued; what follows is the latency-bound scan
+  // the scan (:273-279) without materialising the cross-scan
+  Tensor out4 = at::empty({Bsz, 4 * D, L}, o), x_chk;
+  const int chunk = mm_scan_chunk();
+  if (need_grad) x_chk = at::empty({Bsz, (L + chunk - 1) / chunk, 4 * D, N}, o);
+  {
+    mm_scan_args a = {};
+    fill_common(a, u2, delta, s.A, xb.narrow(2, R, N), xb.narrow(2, R + N, N), s.Dp, s.bias);
+    a.out = fpm(out4); a.x_chk = fpm(x_chk); a.variant = (int32_t)variant;
+    if (ev0) check(mm_event_record(reinterpret_cast<void*>(ev0), stream), "mm_event_record");
+    check(mm_scan_fwd(&a, stream), "mm_scan_fwd");
+    if (ev1) check(mm_event_record(reinterpret_cast<void*>(ev1), stream), "mm_event_record");
+  }
+  // cross-merge (:282-286, 298), out_norm + gate (:299-301)
+  Tensor m = planes(Bsz, D, L, o, cm), y = planes(Bsz, D, L, o, cm);
+  Tensor mu = at::empty({Bsz, L}, o), rstd = at::empty({Bsz, L}, o);
+  check(mm_cross_merge_fwd(fp(out4), fpm(m), m.stride(0), m.stride(1), (int)Bsz, (int)D, (int)H, (int)W, stream), "mm_cross_merge_fwd");
+  check(mm_ln_gate_fwd(fp(m), m.stride(0), m.stride(1), fp(z_cf), z_cf.stride(0), z_cf.stride(1), fp(ln_w), fp(ln_b), (float)eps, fpm(y),
+                       y.stride(0), y.stride(1), fpm(mu), fpm(rstd), (int)Bsz, (int)D, (int)L, stream), "mm_ln_gate_fwd");
+  // out_proj (:302)
+  Tensor out;
+  if (cm && Bsz > 1) {
+    out = at::empty({out_w.size(0), Q}, o);
+    at::mm_out(out, out_w, cm2d(y));
+    out = out.view({-1, Bsz, L}).permute({1, 0, 2});
+  } else {
+    out = at::empty({Bsz, out_w.size(0), L}, o);
+    at::bmm_out(out, out_w.unsqueeze(0).expand({Bsz, -1, -1}), y);
+  }
+  if (!need_grad) return {out};
+  return {out, xz, u2, x_dbl, delta, P, x_chk, m, mu, rstd, y};
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// backward.  Returns {dx (B, L, d_model), d in_w, d conv_w, d conv_b, d x_proj_w, d dt_w, d dt_b, d A_logs, d Ds, d ln_w, d ln_b,
+// d out_w}
+// ---------------------------------------------------------------------------------------------------------------------
+std::vector<Tensor> ss2d_bwd(const Tensor& dout_, const Tensor& x, const Tensor& in_w, const Tensor& conv_w,
+                             const c10::optional<Tensor>& conv_b_, const Tensor& ln_w, const Tensor& ln_b, const Tensor& out_w,
+                             const Tensor& xz, const Tensor& u2, const Tensor& x_dbl, const Tensor& delta, const Tensor& P,
+                             const Tensor& x_chk, const Tensor& m, const Tensor& mu, const Tensor& rstd, const Tensor& y, int64_t H,
+                             int64_t W, bool cm, bool pack_fold, int64_t variant, int64_t stream_, int64_t ev0, int64_t ev1) {
+  void* stream = reinterpret_cast<void*>(stream_);
+  const Tensor conv_b = conv_b_.has_value() ? *conv_b_ : Tensor();
+  const int64_t Bsz = x.size(0), L = x.size(1), dm = x.size(2);
+  const int64_t D = in_w.size(0) / 2, N = 16;
+  const int64_t C = cm ? x_dbl.size(1) : x_dbl.size(2), R = C - 2 * N, Q = Bsz * L;
+  const auto o = x.options();
+  const Seg s = segments(P, D, C, R, N);
+  const Tensor x_cf = xz.narrow(1, 0, D), z_cf = xz.narrow(1, D, D);
+  // out_proj backward
+  Tensor dy, d_out_w;
+  if (cm && Bsz > 1 && is_cm(dout_)) {
+    const Tensor g2 = cm2d(dout_);                                                        // (d_model, Q)
+    dy = at::empty({D, Q}, o);
+    at::mm_out(dy, out_w.t(), g2);
+    dy = dy.view({D, Bsz, L}).permute({1, 0, 2});
+    d_out_w = at::empty({out_w.size(0), D}, o);
+    at::mm_out(d_out_w, g2, cm2d(y).t());
+  } else {
+    const Tensor g = rows(dout_);
+    dy = at::empty({Bsz, D, L}, o);
+    at::bmm_out(dy, out_w.t().unsqueeze(0).expand({Bsz, -1, -1}), g);
+    d_out_w = at::bmm(g, rows(y).transpose(1, 2)).sum(0);
+  }
+  // out_norm + gate backward, its plane transpose for the column-major directions
+  Tensor dout2 = planes(Bsz, 2 * D, L, o, cm);            // channel block 0: dm, block 1: its plane transpose
+  Tensor dxz = planes(Bsz, 2 * D, L, o, cm);              // d(x_cf) | d(z_cf), the layout in_proj produced them in
+  Tensor dz = dxz.narrow(1, D, D);
+  Tensor ws = at::empty({mm_ln_gate_rows((int)Bsz, (int)D, (int)L), 2 * D}, o);
+  check(mm_ln_gate_bwd(fp(dy), dy.stride(0), dy.stride(1), fp(m), m.stride(0), m.stride(1), fp(z_cf), z_cf.stride(0), z_cf.stride(1),
+                       fp(ln_w), fp(ln_b), fp(mu), fp(rstd), fpm(dout2), dout2.stride(0), dout2.stride(1), fpm(dz), dz.stride(0),
+                       dz.stride(1), fpm(ws), (int)Bsz, (int)D, (int)L, stream), "mm_ln_gate_bwd");
+  {
+    Tensor d1 = dout2.narrow(1, D, D);
+    check(mm_plane_transpose(fp(dout2), dout2.stride(0), dout2.stride(1), fpm(d1), d1.stride(0), d1.stride(1), (int)Bsz, (int)D, (int)H,
+                             (int)W, stream), "mm_plane_transpose");
+  }
+  // packed parameter gradients: the GEMMs write the two weight segments, the scan kernel per-batch-item partials of A / D / bias
+  Tensor dP = at::empty_like(P);
+  const Seg ds = segments(dP, D, C, R, N);
+  const int64_t S = mm_ss2d_pack_parts_size((int)D, (int)C, (int)R, (int)N);
+  Tensor parts = at::empty({Bsz, S}, o);
+  Tensor dx_dbl, xb, dxb;
+  if (cm) {
+    dx_dbl = at::empty({4, C, Q}, o);
+    xb = x_dbl.view({4, C, Bsz, L}).permute({2, 0, 1, 3});
+    dxb = dx_dbl.view({4, C, Bsz, L}).permute({2, 0, 1, 3});
+  } else {
+    dx_dbl = at::empty({Bsz, 4, C, L}, o);
+    xb = x_dbl; dxb = dx_dbl;
+  }
+  // scan backward (selective_scan_interface._launch_bwd)
+  Tensor du4 = planes(Bsz, 4 * D, L, o, cm), ddelta = planes(Bsz, 4 * D, L, o, cm);
+  {
+    const Tensor Bm = xb.narrow(2, R, N), Cm = xb.narrow(2, R + N, N);
+    Tensor dBC = dxb.narrow(2, R, 2 * N);                  // rows [0, N): dB, rows [N, 2N): dC; fully overwritten
+    mm_scan_args a = {};
+    fill_common(a, u2, delta, s.A, Bm, Cm, s.Dp, s.bias);
+    a.x_chk = fpm(x_chk); a.dout = fp(dout2);
+    a.du = fpm(du4); a.ddelta = fpm(ddelta);
+    a.dA = fpm(parts); a.dD = fpm(parts) + (s.oD - s.oA); a.ddelta_bias = fpm(parts) + (s.ob - s.oA);
+    a.dpar_sb = parts.stride(0);
+    a.dout_sb = dout2.stride(0); a.dud_sb = du4.stride(0); a.o_sd = du4.stride(1);
+    TORCH_CHECK(dout2.stride(1) == du4.stride(1), "dout and du / ddelta must share the channel stride");
+    a.variant = (int32_t)variant;
+    auto point = [&](const Tensor& t, int64_t plane_stride) {
+      a.dB = fpm(t); a.dC = fpm(t) + N * t.stride(2);
+      a.dB_sb = a.dC_sb = t.stride(0); a.dB_sg = a.dC_sg = t.stride(1); a.dB_sn = a.dC_sn = t.stride(2);
+      a.dBC_sc = plane_stride;
+    };
+    point(dBC, 0);
+    int32_t plan[8];
+    check(mm_scan_plan(&a, 1, plan), "mm_scan_plan");
+    Tensor pl;
+    if (plan[6] > 1) {        // a direction is shared by W workgroups: one partial plane each, summed below
+      pl = like_strided(dBC, plan[6]);
+      point(pl.select(0, 0), pl.stride(0));
+    }
+    if (ev0) check(mm_event_record(reinterpret_cast<void*>(ev0), stream), "mm_event_record");
+    check(mm_scan_bwd(&a, stream), "mm_scan_bwd");
+    if (ev1) check(mm_event_record(reinterpret_cast<void*>(ev1), stream), "mm_event_record");
+    if (pl.defined()) at::sum_out(dBC, pl, DIM0);
+  }
+  Tensor du2;
+  if (cm) {
+    const Tensor dd = ddelta.permute({1, 0, 2}).reshape({4, D, Q});                        // views of (4D, B, L) storage
+    Tensor dWdt = ds.Wdt, dxr = dx_dbl.narrow(1, 0, R);
+    at::bmm_out(dWdt, dd, x_dbl.narrow(1, 0, R).transpose(1, 2));                          // (4, D, R)
+    at::bmm_out(dxr, s.Wdt.transpose(1, 2), dd);                                          // dt rows of d(x_dbl), in place
+    const Tensor dx2 = dx_dbl.view({2, 2 * C, Q});
+    Tensor du2m = at::empty({2, D, Q}, o);
+    at::bmm_out(du2m, s.Wx.view({2, 2 * C, D}).transpose(1, 2), dx2);                      // Wx^T d(x_dbl); pairs added later
+    Tensor dWx = ds.Wx.view({2, 2 * C, D});
+    at::bmm_out(dWx, dx2, cm2d(u2).view({2, D, Q}).transpose(1, 2));
+    du2 = du2m.view({2 * D, Bsz, L}).permute({1, 0, 2});
+  } else {
+    const Tensor dd = ddelta.view({Bsz, 4, D, L});
+    const Tensor xr = x_dbl.narrow(2, 0, R);
+    Tensor dWdt = ds.Wdt;
+    at::sum_out(dWdt, at::matmul(dd, xr.transpose(-1, -2)), DIM0);                          // (4, D, R)
+    dx_dbl.narrow(2, 0, R).copy_(at::matmul(s.Wdt.transpose(-1, -2).unsqueeze(0), dd));    // dt rows of d(x_dbl)
+    const Tensor Wx2 = s.Wx.view({2, 2 * C, D});
+    const Tensor dxd2 = dx_dbl.view({Bsz, 2, 2 * C, L});
+    const Tensor WxT = Wx2.transpose(1, 2).unsqueeze(0).expand({Bsz, -1, -1, -1}).reshape({Bsz * 2, D, 2 * C});
+    du2 = at::bmm(WxT, dxd2.reshape({Bsz * 2, 2 * C, L}));                                 // Wx^T d(x_dbl); pairs added later
+    Tensor dWx = ds.Wx.view({2, 2 * C, D});
+    at::sum_out(dWx, at::matmul(dxd2, u2.view({Bsz, 2, D, L}).transpose(-1, -2)), DIM0);
+    du2 = du2.view({Bsz, 2 * D, L});
+  }
+  // d(u2) = projection part + the scan's two direction pairs, summed inside the depthwise conv's backward kernel
+  Tensor dxc = dxz.narrow(1, 0, D);
+  const int strips = mm_dwconv_silu_cross_strips((int)H, (int)W);
+  Tensor wsc = at::empty({Bsz, D * strips, 10}, o);
+  check(mm_dwconv_silu_cross_bwd(fp(du2), du2.stride(0), du2.stride(1), fp(du4), du4.stride(0), du4.stride(1), fp(x_cf), x_cf.stride(0),
+                                 x_cf.stride(1), fp(conv_w), fp(conv_b), fpm(dxc), dxc.stride(0), dxc.stride(1), fpm(wsc), (int)Bsz, (int)D,
+                                 (int)H, (int)W, stream), "mm_dwconv_silu_cross_bwd");
+  // one launch: packed gradients back to the module's layouts, ln_gate's partial rows, the depthwise conv's partial sums
+  const int64_t npk = P.numel();
+  Tensor G = at::empty({npk + 2 * D + 10 * D}, o);
+  Tensor ln_out = G.narrow(0, npk, 2 * D), dw_out = G.narrow(0, npk + 2 * D, 10 * D);
+  check(mm_ss2d_pack_bwd(fp(dP), fp(P), fp(parts), fpm(G), (int)D, (int)C, (int)R, (int)N, (int)Bsz, pack_fold ? fp(ws) : nullptr,
+                         (int)ws.size(0), fpm(ln_out), pack_fold ? fp(wsc) : nullptr, (int)Bsz, strips, fpm(dw_out), stream),
+        "mm_ss2d_pack_bwd");
+  const Seg gs = segments(G.narrow(0, 0, npk), D, C, R, N);
+  if (!pack_fold) {                                     // A/B switch (MM_PACK_FOLD=0): the reductions as separate ATen launches
+    ln_out = ws.sum(0);
+    const Tensor sc = wsc.view({Bsz, D, -1, 10}).sum(at::IntArrayRef({0, 2}));
+    dw_out = at::cat({sc.narrow(1, 0, 9).reshape({-1}), sc.select(1, 9)});
+  }
+  Tensor dcw = dw_out.narrow(0, 0, 9 * D).view({D, 1, 3, 3});
+  Tensor dcb = conv_b.defined() ? dw_out.narrow(0, 9 * D, D) : Tensor();
+  // in_proj backward: one GEMM per product over all 2D rows
+  Tensor dx, d_in_w = at::empty_like(in_w);
+  if (cm && is_cm(dxz)) {
+    const Tensor g2 = cm2d(dxz), x2 = x.view({Q, dm});
+    dx = at::empty({Q, dm}, o);
+    at::mm_out(dx, g2.t(), in_w);
+    dx = dx.view({Bsz, L, dm});
+    at::mm_out(d_in_w, g2, x2);
+  } else {
+    dx = at::empty({Bsz, L, dm}, o);
+    at::bmm_out(dx, dxz.transpose(1, 2), in_w.unsqueeze(0).expand({Bsz, -1, -1}));
+    at::sum_out(d_in_w, at::bmm(dxz, x), DIM0);
+  }
+  return {dx, d_in_w, dcw, dcb, gs.Wx, gs.Wdt, gs.bias.view({4, D}), gs.A, gs.Dp, ln_out.narrow(0, 0, D), ln_out.narrow(0, D, D), d_out_w};
+}
+
+}  // namespace
+
+PYBIND11_MODULE(TORCH_EXTENSION_NAME, mod) {
+  mod.doc() = "medmamba_amd: C++ sequencing of the SS2D branch over the C ABI of libmedmamba_hip.so";
+  mod.def("ss2d_fwd", &ss2d_fwd);
+  mod.def("ss2d_bwd", &ss2d_bwd);
+  mod.def("abi_version", []() { return mm_abi_version(); });
+}

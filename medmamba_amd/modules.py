@@ -338,13 +338,22 @@ class SS2D(nn.Module):
         transpose copies (MedMamba.py:294-299) exists."""
         B, H, W, _ = x.shape
         L, D, R, N = H * W, self.d_inner, self.dt_rank, self.d_state
+        cv = self.conv2d
+        conv_ok = (cv.kernel_size == (3, 3) and cv.padding == (1, 1) and cv.stride == (1, 1) and cv.dilation == (1, 1)
+                   and cv.groups == D and cv.padding_mode == "zeros" and _lib.lib().mm_dwconv_silu_cross_supported(H, W))
+        if conv_ok and ops.ss2d_branch_native_ok(x, self.in_proj, self.out_proj, cv, (
+                self.x_proj_weight, self.dt_projs_weight, self.dt_projs_bias, self.A_logs, self.Ds, self.out_norm.weight,
+                self.out_norm.bias)):
+            # training: the whole branch as ONE autograd node, sequenced in C++ (csrc_host/ss2d_host.cpp) — same launches as below
+            out = ops.ss2d_branch(x.reshape(B, L, -1), self.in_proj.weight, cv.weight, cv.bias, self.x_proj_weight,
+                                  self.dt_projs_weight, self.dt_projs_bias, self.A_logs, self.Ds, self.out_norm.weight,
+                                  self.out_norm.bias, self.out_proj.weight, H, W, self.out_norm.eps, prescan_event=prescan_event)
+            return out if self.dropout is None else self.dropout(out)
         x_cf, z_cf = in_proj_cf(x.reshape(B, L, -1), self.in_proj.weight, self.in_proj.bias)  # :291-292, (B, D, L) each
         # depthwise conv + SiLU (:294-295) writing both image orders of :256, projections (:259-262), A = -exp(A_logs)
         # (:271), scan, merge, out_norm and gate (:273-301) — one autograd Function; the parameters go in as the module
         # holds them, the kernel-order packing is one launch inside
-        cv = self.conv2d
-        if cv.kernel_size == (3, 3) and cv.padding == (1, 1) and cv.stride == (1, 1) and cv.dilation == (1, 1) \
-                and cv.groups == D and cv.padding_mode == "zeros" and _lib.lib().mm_dwconv_silu_cross_supported(H, W):
+        if conv_ok:
             y_cf = ss2d_conv_core(x_cf, cv.weight, cv.bias, self.x_proj_weight, self.dt_projs_weight, self.dt_projs_bias,
                                   self.A_logs, self.Ds, z_cf, self.out_norm.weight, self.out_norm.bias, H, W,
                                   self.out_norm.eps, prescan_event=prescan_event)

@@ -518,6 +518,69 @@ class SS2DCoreFn(torch.autograd.Function):
         return (du2, dcw, dcb, gWx, gWdt, gb.view(4, D), gA, gD, dz, ln_out[:D], ln_out[D:], None, None, None, None)
 
 
+class SS2DBranchFn(torch.autograd.Function):
+    """The whole SS2D branch (MedMamba.py:288-305 without dropout) as one autograd node whose forward and backward are ONE call
+    each into the C++ sequencing layer (csrc_host/ss2d_host.cpp): x (B, L, d_model) rows -> (B, d_model, L) planes.  Same
+    kernels, GEMMs, allocations and layouts as InProjFn + SS2DCoreFn (fused depthwise conv) + OutProjFn, issued without the
+    interpreter between the launches (0.2 + 0.4 ms of host time per block and step)."""
+
+    @staticmethod
+    def forward(ctx, x, in_w, conv_w, conv_b, x_proj_w, dt_w, dt_b, A_logs, Ds, ln_w, ln_b, out_w, H, W, eps, prescan_event):
+        from . import _host
+        from .selective_scan_interface import KERNEL_TIMER, _FWD_VARIANT, scan_bytes_fwd
+        Bsz, L, _ = x.shape
+        D, N = in_w.shape[0] // 2, A_logs.shape[1]
+        cm = channel_major(Bsz, L)
+        need_grad = any(ctx.needs_input_grad)
+        x = x.contiguous()
+        with _lib.device_guard(x.device):
+            ev0, ev1 = KERNEL_TIMER.pair("scan_fwd", scan_bytes_fwd(Bsz, 4 * D, L, N, 4), Bsz * 4 * D * L * N)
+            res = _host.module().ss2d_fwd(x, in_w, conv_w, conv_b, x_proj_w, dt_w, dt_b, A_logs, Ds, ln_w, ln_b, out_w, H, W, float(eps),
+                                          cm, need_grad, _FWD_VARIANT, _stream(), ev0, ev1, prescan_event)
+        if need_grad:
+            ctx.save_for_backward(x, in_w, conv_w, conv_b, ln_w, ln_b, out_w, *res[1:])
+            ctx.dims = (H, W, cm)
+        return res[0]
+
+    @staticmethod
+    def backward(ctx, dout):
+        from . import _host
+        from .selective_scan_interface import KERNEL_TIMER, _BWD_VARIANT, scan_bytes_bwd
+        x, in_w, conv_w, conv_b, ln_w, ln_b, out_w, xz, u2, x_dbl, delta, P, x_chk, m, mu, rstd, y = ctx.saved_tensors
+        H, W, cm = ctx.dims
+        Bsz, L, _ = x.shape
+        D = in_w.shape[0] // 2
+        with _lib.device_guard(x.device):
+            ev0, ev1 = KERNEL_TIMER.pair("scan_bwd", scan_bytes_bwd(Bsz, 4 * D, L, 16, 4), Bsz * 4 * D * L * 16)
+            g = _host.module().ss2d_bwd(dout, x, in_w, conv_w, conv_b, ln_w, ln_b, out_w, xz, u2, x_dbl, delta, P, x_chk, m, mu, rstd, y,
+                                        H, W, cm, _PACK_FOLD, _BWD_VARIANT, _stream(), ev0, ev1)
+        dx, d_in, dcw, dcb, gWx, gWdt, gb, gA, gD, dlw, dlb, d_out = g
+        return dx, d_in, dcw, dcb, gWx, gWdt, gb, gA, gD, dlw, dlb, d_out, None, None, None, None
+
+
+def ss2d_branch_native_ok(x, mod_in_proj, mod_out_proj, conv, params):
+    """True when SS2DBranchFn can take the whole branch: the extension is built, fp32 contiguous parameters, no biases on the two
+    projections (MedMamba.py:139, 181: bias=False by default), gradients wanted (inference keeps the route with the fused dt
+    projection)."""
+    from . import _host
+    if _host.module() is None or not torch.is_grad_enabled() or not x.is_cuda or x.dtype != torch.float32:
+        return False
+    if mod_in_proj.bias is not None or mod_out_proj.bias is not None:
+        return False
+    ts = [mod_in_proj.weight, mod_out_proj.weight, conv.weight, *params] + ([] if conv.bias is None else [conv.bias])
+    return all(t.dtype == torch.float32 and t.is_contiguous() and t.is_cuda for t in ts)
+
+
+def ss2d_branch(x_rows, in_w, conv_w, conv_b, x_proj_w, dt_w, dt_b, A_logs, Ds, ln_w, ln_b, out_w, H, W, eps=1e-5, prescan_event=None):
+    D = in_w.shape[0] // 2
+    if (A_logs.shape != (4 * D, 16) or x_proj_w.shape[0] != 4 or x_proj_w.shape[2] != D or dt_w.shape[:2] != (4, D)
+            or dt_b.shape != (4, D) or Ds.shape != (4 * D,) or x_proj_w.shape[1] != dt_w.shape[2] + 32
+            or tuple(conv_w.shape) != (D, 1, 3, 3) or out_w.shape[1] != D):
+        raise NotImplementedError("ss2d_branch: expects 4 directions, d_state 16, a depthwise 3x3 conv over d_inner channels")
+    return SS2DBranchFn.apply(x_rows, in_w, conv_w, conv_b, x_proj_w, dt_w, dt_b, A_logs, Ds, ln_w, ln_b, out_w, H, W, eps,
+                              prescan_event)
+
+
 def ss2d_core(u2, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds, z_cf, ln_w, ln_b, H, W, eps=1e-5,
               prescan_event=None):
     """Parameters in the module's own (reference) layout and direction order; see SS2DCoreFn.

@@ -51,10 +51,14 @@ class FusedAdamW(torch.optim.AdamW):
             return out
         if self._plans is False:
             return super().step()
-        for group, params, exp_avgs, exp_avg_sqs, steps in self._plans:
+        all_grads = []
+        for _, params, *_ in self._plans:
             grads = [p.grad for p in params]
-            if None in grads:                          # a parameter without a gradient this step: torch's general path
-                return super().step()
+            for g in grads:
+                if g is None:                          # a parameter without a gradient this step: torch's general path
+                    return super().step()
+            all_grads.append(grads)
+        for (group, params, exp_avgs, exp_avg_sqs, steps), grads in zip(self._plans, all_grads):
             beta1, beta2 = group["betas"]
             torch._foreach_add_(steps, 1)
             torch._fused_adamw_(params, grads, exp_avgs, exp_avg_sqs, [], steps, amsgrad=False, lr=group["lr"], beta1=beta1,

@@ -41,6 +41,17 @@ class _KernelTimer:
         end.record()
         self.records.append((tag, start, end, nbytes, nsteps))
 
+    def pair(self, tag, nbytes, nsteps=0):
+        """For a launch that happens inside a native call: two timing events, as raw hipEvent_t handles, which the callee
+        records around the kernel on the launch stream (mm_event_record).  (0, 0) when the timer is off."""
+        if not self.enabled:
+            return 0, 0
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        e.record()             # torch creates the hipEvent at its first record; the callee records both again
+        self.records.append((tag, s, e, nbytes, nsteps))
+        return s.cuda_event, e.cuda_event
+
     def summary(self):
         """{tag: dict(calls, ms, bytes)} — call only after torch.cuda.synchronize()."""
         out = {}

@@ -552,3 +552,47 @@ def test_vssm_constructor_variants_fused_vs_hooked_path(kw):
     assert y.shape == (2, 4)
     _close(y, y2.detach().cpu().numpy(), 1e-4, "logits")
     _close(g, x.grad.cpu().numpy(), 1e-3, "dx")
+
+
+@pytest.mark.parametrize("layout", ["bm", "cm"])
+def test_cpp_sequenced_ss2d_branch_is_the_python_route_bit_for_bit(layout, monkeypatch):
+    """csrc_host/ss2d_host.cpp issues the launches of InProjFn + SS2DCoreFn + OutProjFn from C++: same kernels, same GEMM shapes,
+    same allocations — output, input gradient and all eleven parameter gradients are identical bits in both storage layouts."""
+    from medmamba_amd import _host, modules, ops
+    from medmamba_amd.selective_scan_interface import KERNEL_TIMER
+    assert _host.module() is not None, "lib/_mm_host.so is missing: python -m medmamba_amd.build"
+    torch.manual_seed(21)
+    ss = modules.SS2D(d_model=24, d_state=16, expand=2).to(DEV).train()
+    monkeypatch.setattr(ops, "_LAYOUT", layout)
+    x = torch.randn(3, 12, 8, 24, device=DEV, requires_grad=True)
+    g = torch.randn(3, 24, 96, device=DEV)
+    calls = []
+    real = ops.SS2DBranchFn.apply
+    monkeypatch.setattr(ops.SS2DBranchFn, "apply", lambda *a: (calls.append(1), real(*a))[1])
+
+    def run(native):
+        if not native:
+            monkeypatch.setattr(ops, "ss2d_branch_native_ok", lambda *a: False)
+        ss.zero_grad(set_to_none=True)
+        x.grad = None
+        out = ss.forward_cf(x)
+        out.backward(g)
+        return out.detach().clone(), x.grad.clone(), {k: p.grad.clone() for k, p in ss.named_parameters()}
+
+    KERNEL_TIMER.records.clear()
+    KERNEL_TIMER.enabled = True
+    try:
+        o1, dx1, g1 = run(True)
+        torch.cuda.synchronize()
+        tags = [r[0] for r in KERNEL_TIMER.records]
+        assert tags == ["scan_fwd", "scan_bwd"] and all(s.elapsed_time(e) > 0 for _, s, e, *_ in KERNEL_TIMER.records)
+    finally:
+        KERNEL_TIMER.enabled = False
+        KERNEL_TIMER.records.clear()
+    assert calls == [1]
+    o0, dx0, g0 = run(False)
+    assert calls == [1]
+    assert torch.equal(o1, o0) and torch.equal(dx1, dx0)
+    assert set(g1) == set(g0) and len(g0) == 11
+    for k in g0:
+        assert torch.equal(g1[k], g0[k]), k
