@@ -325,9 +325,96 @@ std::vector<Tensor> ss2d_bwd(const Tensor& dout_, const Tensor& x, const Tensor&
   return {dx, d_in_w, dcw, dcb, gs.Wx, gs.Wdt, gs.bias.view({4, D}), gs.A, gs.Dp, ln_out.narrow(0, 0, D), ln_out.narrow(0, D, D), d_out_w};
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The conv branch of a block (MedMamba.py:338-345 without the trailing ReLU and without the 1x1 conv's bias, both applied by
+// mm_shuffle_residual_fwd): BN1 -> conv3x3 -> BN2 + ReLU -> conv3x3 -> BN3 + ReLU -> conv1x1, the sequence
+// modules._conv_branch issues through BNReluFn / ConvBiasFn(add_bias=False) / PointwiseConvFn, statement by statement.
+// The 3x3 convolutions stay ATen's (MIOpen); the conv biases act only through the BatchNorm running means (pre_bias).
+// ---------------------------------------------------------------------------------------------------------------------
+struct BnP { Tensor g, b, rm, rv; double eps, mom; };
+
+inline std::pair<Tensor, Tensor> bn_fwd(const Tensor& x, const BnP& p, bool relu, const Tensor& pre_bias, void* stream) {
+  const int64_t B = x.size(0), C = x.size(1), HW = x.numel() / (B * C);
+  Tensor y = at::empty_like(x), stats = at::empty({2, C}, x.options());
+  Tensor ws = at::empty({3 * C * mm_bn_splits((int)B, (int)C, (int)HW)}, x.options());
+  check(mm_bn_relu_fwd(fp(x), fp(p.g), fp(p.b), (float)p.eps, (float)p.mom, fpm(p.rm), fpm(p.rv), fpm(y), fpm(stats),
+                       fpm(stats) + C, fpm(ws), fp(pre_bias), relu ? 1 : 0, (int)B, (int)C, (int)HW, stream), "mm_bn_relu_fwd");
+  return {y, stats};
+}
+
+inline Tensor bias_grad(const Tensor& dy, void* stream) {      // ops._bias_grad
+  const int64_t B = dy.size(0), C = dy.size(1), HW = dy.numel() / (B * C);
+  if (HW < 512) return dy.dim() == 4 ? dy.sum(at::IntArrayRef({0, 2, 3})) : dy.sum(at::IntArrayRef({0, 2}));
+  const int split = mm_channel_sum_nchw_split((int)B, (int)C);
+  Tensor out = at::empty({split, C}, dy.options());
+  check(mm_channel_sum_nchw(fp(dy), fpm(out), (int)B, (int)C, (int)HW, stream), "mm_channel_sum_nchw");
+  return split == 1 ? out.select(0, 0) : out.sum(0);
+}
+
+// returns {dx, dgamma, dbeta, d(pre_bias) or undefined}
+inline std::vector<Tensor> bn_bwd(const Tensor& dy_, const Tensor& x, const Tensor& g, const Tensor& b, const Tensor& stats, bool relu,
+                                  bool want_db, void* stream) {
+  const int64_t B = x.size(0), C = x.size(1), HW = x.numel() / (B * C);
+  const Tensor dy = dy_.contiguous();
+  Tensor dx = at::empty_like(x);
+  const bool fused = mm_bn_fused((int)B, (int)C, (int)HW) != 0;
+  Tensor dgb = at::empty({3, C}, x.options());
+  Tensor ws = fused ? dgb : at::empty({2 * C * mm_bn_splits((int)B, (int)C, (int)HW)}, x.options());
+  check(mm_bn_relu_bwd(fp(dy), fp(x), fp(g), fp(b), fp(stats), fp(stats) + C, fpm(dx), fpm(dgb), fpm(dgb) + C, fpm(ws),
+                       (want_db && fused) ? fpm(dgb) + 2 * C : nullptr, relu ? 1 : 0, (int)B, (int)C, (int)HW, stream), "mm_bn_relu_bwd");
+  Tensor db;
+  if (want_db) db = fused ? dgb.select(0, 2) : bias_grad(dx, stream);
+  return {dx, dgb.select(0, 0), dgb.select(0, 1), db};
+}
+
+const int64_t kOne2[2] = {1, 1}, kZero2[2] = {0, 0};
+
+// returns {out (B, K, H, W), y1, s1, c1, y2, s2, c2, y3, s3}
+std::vector<Tensor> conv_branch_fwd(const Tensor& x, const std::vector<Tensor>& bn1, const Tensor& w1, const Tensor& cb1,
+                                    const std::vector<Tensor>& bn2, const Tensor& w2, const Tensor& cb2, const std::vector<Tensor>& bn3,
+                                    const Tensor& w3, const std::vector<double>& eps_mom, int64_t stream_) {
+  void* stream = reinterpret_cast<void*>(stream_);
+  TORCH_CHECK(bn1.size() == 4 && bn2.size() == 4 && bn3.size() == 4 && eps_mom.size() == 6 && x.is_contiguous(), "conv_branch_fwd: arguments");
+  const BnP p1{bn1[0], bn1[1], bn1[2], bn1[3], eps_mom[0], eps_mom[1]}, p2{bn2[0], bn2[1], bn2[2], bn2[3], eps_mom[2], eps_mom[3]},
+      p3{bn3[0], bn3[1], bn3[2], bn3[3], eps_mom[4], eps_mom[5]};
+  const at::IntArrayRef one(kOne2, 2);
+  auto [y1, s1] = bn_fwd(x, p1, false, Tensor(), stream);
+  Tensor c1 = at::conv2d(y1, w1, c10::nullopt, one, one, one, 1);
+  auto [y2, s2] = bn_fwd(c1, p2, true, cb1, stream);
+  Tensor c2 = at::conv2d(y2, w2, c10::nullopt, one, one, one, 1);
+  auto [y3, s3] = bn_fwd(c2, p3, true, cb2, stream);
+  const int64_t B = x.size(0), C = y3.size(1), H = x.size(2), W = x.size(3), K = w3.size(0);
+  Tensor out = at::empty({B, K, H * W}, x.options());
+  at::bmm_out(out, w3.view({K, C}).unsqueeze(0).expand({B, -1, -1}), y3.view({B, C, H * W}));
+  return {out.view({B, K, H, W}), y1, s1, c1, y2, s2, c2, y3, s3};
+}
+
+// returns {dx, dg1, db1, dw1, dcb1, dg2, db2, dw2, dcb2, dg3, db3, dw3}
+std::vector<Tensor> conv_branch_bwd(const Tensor& dout, const Tensor& x, const Tensor& g1, const Tensor& b1, const Tensor& w1,
+                                    const Tensor& g2, const Tensor& b2, const Tensor& w2, const Tensor& g3, const Tensor& b3,
+                                    const Tensor& w3, const Tensor& y1, const Tensor& s1, const Tensor& c1, const Tensor& y2,
+                                    const Tensor& s2, const Tensor& c2, const Tensor& y3, const Tensor& s3, int64_t stream_) {
+  void* stream = reinterpret_cast<void*>(stream_);
+  const int64_t B = x.size(0), H = x.size(2), W = x.size(3), C = y3.size(1), K = w3.size(0);
+  const at::IntArrayRef one(kOne2, 2), zero(kZero2, 2);
+  const Tensor dy = dout.contiguous().view({B, K, H * W});
+  const Tensor w3v = w3.view({K, C}), y3v = y3.view({B, C, H * W});
+  Tensor dy3 = at::empty({B, C, H * W}, x.options());
+  at::bmm_out(dy3, w3v.t().unsqueeze(0).expand({B, -1, -1}), dy);
+  Tensor dw3 = at::bmm(dy, y3v.transpose(1, 2)).sum(0).view(w3.sizes());
+  auto r3 = bn_bwd(dy3.view({B, C, H, W}), c2, g3, b3, s3, true, true, stream);
+  auto cbw2 = at::convolution_backward(r3[0], y2, w2, c10::nullopt, one, one, one, false, zero, 1, {true, true, false});
+  auto r2 = bn_bwd(std::get<0>(cbw2), c1, g2, b2, s2, true, true, stream);
+  auto cbw1 = at::convolution_backward(r2[0], y1, w1, c10::nullopt, one, one, one, false, zero, 1, {true, true, false});
+  auto r1 = bn_bwd(std::get<0>(cbw1), x, g1, b1, s1, false, false, stream);
+  return {r1[0], r1[1], r1[2], std::get<1>(cbw1), r2[3], r2[1], r2[2], std::get<1>(cbw2), r3[3], r3[1], r3[2], dw3};
+}
+
 }  // namespace
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, mod) {
+  mod.def("conv_branch_fwd", &conv_branch_fwd);
+  mod.def("conv_branch_bwd", &conv_branch_bwd);
   mod.doc() = "medmamba_amd: C++ sequencing of the SS2D branch over the C ABI of libmedmamba_hip.so";
   mod.def("ss2d_fwd", &ss2d_fwd);
   mod.def("ss2d_bwd", &ss2d_bwd);

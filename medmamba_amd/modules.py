@@ -553,7 +553,13 @@ class SS_Conv_SSM(nn.Module):
         last = mods[-1] if mods else None
         defer_bias = (fold_relu and not graph_conv and input.is_cuda and last is not None and _is_pointwise(last)
                       and last.bias is not None)
-        conv_body = lambda t: _conv_branch(mods, t, skip_last_bias=defer_bias)
+        def conv_body(t):
+            if defer_bias and _OWN_BN:       # the reference's conv branch in training mode: one C++-sequenced autograd node
+                y = ops.conv_branch_native(mods, t)
+                if y is not None:
+                    return y
+            return _conv_branch(mods, t, skip_last_bias=defer_bias)
+
         if graph_conv:
             conv_body = self._graphed_conv_body(mods, left)
         # PyTorch asks MIOpen to FIND a solver at the first call of every conv configuration, and MIOpen answers by timing its

@@ -969,6 +969,65 @@ class BNReluFn(torch.autograd.Function):
         return dx, dgb[0], dgb[1], None, None, None, None, None, None, db
 
 
+class ConvBranchFn(torch.autograd.Function):
+    """The conv branch of SS_Conv_SSM (MedMamba.py:338-345; the trailing ReLU and the 1x1 conv's bias are shuffle_residual's) as one
+    autograd node, its forward and backward ONE call each into csrc_host/ss2d_host.cpp (conv_branch_fwd / _bwd): the launches of
+    BNReluFn x 3, ConvBiasFn(add_bias=False) x 2 and PointwiseConvFn, without the interpreter and five autograd nodes in between.
+    Running statistics are updated by the kernels; the caller (conv_branch_native) advances the counters and version numbers."""
+
+    @staticmethod
+    def forward(ctx, x, g1, b1, w1, cb1, g2, b2, w2, cb2, g3, b3, w3, buffers, eps_mom):
+        from . import _host
+        with _lib.device_guard(x.device):
+            res = _host.module().conv_branch_fwd(x, [g1, b1, buffers[0], buffers[1]], w1, cb1, [g2, b2, buffers[2], buffers[3]], w2, cb2,
+                                                 [g3, b3, buffers[4], buffers[5]], w3, eps_mom, _stream())
+        ctx.save_for_backward(x, g1, b1, w1, g2, b2, w2, g3, b3, w3, *res[1:])
+        return res[0]
+
+    @staticmethod
+    def backward(ctx, dout):
+        from . import _host
+        t = ctx.saved_tensors
+        with _lib.device_guard(dout.device):
+            g = _host.module().conv_branch_bwd(dout, *t, _stream())
+        return (*g, None, None)
+
+
+def conv_branch_native(mods, x):
+    """`mods` = the conv branch without its trailing ReLU (8 modules).  Returns the pre-activation of that ReLU WITHOUT the 1x1 conv's
+    bias through ConvBranchFn, or None when the branch is not the reference's BN-conv3x3-BN-ReLU-conv3x3-BN-ReLU-conv1x1 in
+    training mode on fp32 HIP tensors (the caller then walks the modules one by one)."""
+    from . import _host
+    nn = torch.nn
+    if (_host.module() is None or len(mods) != 8 or not torch.is_grad_enabled() or not x.is_cuda or x.dtype != torch.float32
+            or x.dim() != 4 or _OWN_CONV or torch.cuda.is_current_stream_capturing()):
+        return None
+    bn1, c1, bn2, r2, c2, bn3, r3, c3 = mods
+    if type(r2) is not nn.ReLU or type(r3) is not nn.ReLU:
+        return None
+    for bn in (bn1, bn2, bn3):
+        if not (type(bn) is nn.BatchNorm2d and bn.training and bn.affine and bn.track_running_stats and bn.momentum is not None
+                and bn.num_batches_tracked is not None and bn.weight.dtype == torch.float32):
+            return None
+    for c in (c1, c2):
+        if not (type(c) is nn.Conv2d and c.kernel_size == (3, 3) and c.stride == (1, 1) and c.padding == (1, 1) and c.dilation == (1, 1)
+                and c.groups == 1 and c.padding_mode == "zeros" and c.bias is not None and c.weight.dtype == torch.float32):
+            return None
+    if not (type(c3) is nn.Conv2d and c3.kernel_size == (1, 1) and c3.stride == (1, 1) and c3.padding == (0, 0) and c3.groups == 1
+            and c3.padding_mode == "zeros" and c3.weight.dtype == torch.float32):
+        return None
+    bns = (bn1, bn2, bn3)
+    if _DEFERRED_COUNTERS is not None:
+        _DEFERRED_COUNTERS.extend(bn.num_batches_tracked for bn in bns)
+    else:
+        torch._foreach_add_([bn.num_batches_tracked for bn in bns], 1)
+    buffers = [t for bn in bns for t in (bn.running_mean, bn.running_var)]
+    y = ConvBranchFn.apply(x.contiguous(), bn1.weight, bn1.bias, c1.weight, c1.bias, bn2.weight, bn2.bias, c2.weight, c2.bias,
+                           bn3.weight, bn3.bias, c3.weight, buffers, [bn1.eps, bn1.momentum, bn2.eps, bn2.momentum, bn3.eps, bn3.momentum])
+    torch.autograd.graph.increment_version(buffers)      # updated through raw pointers (see bn_relu_train)
+    return y
+
+
 _DEFERRED_COUNTERS = None      # list while a caller batches the BatchNorm step counters of a whole forward (VSSM.forward_backbone)
 
 

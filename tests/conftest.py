@@ -29,8 +29,9 @@ def split_sd(fx, prefix="sd/"):
 def _built_library():
     """Build libmedmamba_hip.so (hipcc cross-compiles without a GPU) and the C oracle once per session.  build() is
     incremental on source / header mtimes, so edited kernels are never tested against a stale binary."""
-    from medmamba_amd.build import build
+    from medmamba_amd.build import build, build_host
     build()
+    build_host()          # the C++ sequencing layer (g++, ~90 s when its source or the header changed, otherwise nothing)
     from oracle.scan_ref import build_c_oracle
     build_c_oracle()
 

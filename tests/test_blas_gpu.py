@@ -58,6 +58,9 @@ def test_operand_forms_match_torch(direct):
 @pytest.mark.parametrize("layout", ["bm", "cm"])
 def test_tiny_model_direct_route_matches_torch_route(layout, monkeypatch, capsys):
     from medmamba_amd import blas, modules, ops
+    # the Python route of the projections is what calls blas.gemm (the C++-sequenced branches issue their GEMMs through ATen)
+    monkeypatch.setattr(ops, "ss2d_branch_native_ok", lambda *a: False)
+    monkeypatch.setattr(ops, "conv_branch_native", lambda *a: None)
     torch.manual_seed(5)
     net = modules.VSSM(num_classes=4, depths=[1, 1, 1, 1], dims=[16, 32, 64, 128], drop_path_rate=0.0).to(DEV).train()
     x = torch.randn(3, 3, 64, 64, device=DEV)
@@ -84,11 +87,13 @@ def test_tiny_model_direct_route_matches_torch_route(layout, monkeypatch, capsys
         assert (g1[k] - g0[k]).abs().max().item() <= 2e-3 * scale, (layout, k)
 
 
-def test_recorded_solutions_are_used_at_full_size():
+def test_recorded_solutions_are_used_at_full_size(monkeypatch):
     """The shapes of MedMamba-S at 64 x 224^2 are in the table with the rocBLAS build of this image: one 14x14 block (channel-major
     planes) sends its projections through the recorded solutions and agrees with the torch route."""
-    from medmamba_amd import blas, modules
+    from medmamba_amd import blas, modules, ops
     from medmamba_amd.tuning import enable_tuned_gemms
+    monkeypatch.setattr(ops, "ss2d_branch_native_ok", lambda *a: False)
+    monkeypatch.setattr(ops, "conv_branch_native", lambda *a: None)
     enable_tuned_gemms()
     if not blas._TABLE:
         pytest.skip("GEMM table not recorded for this rocBLAS build")
@@ -118,6 +123,8 @@ def test_recorded_solutions_are_used_at_full_size():
         assert torch.allclose(o1, o0, rtol=1e-4, atol=1e-4)
         assert (dx1 - dx0).abs().max().item() <= 2e-3 * dx0.abs().max().item()
         for k in g0:
+            if k in ("conv33conv33conv11.1.bias", "conv33conv33conv11.4.bias"):
+                continue          # a conv bias in front of a BatchNorm: the true gradient is exactly zero, what is computed is rounding noise
             assert (g1[k] - g0[k]).abs().max().item() <= 2e-3 * max(1e-4, g0[k].abs().max().item()), k
     finally:
         torch.cuda.tunable.enable(False)

@@ -596,3 +596,51 @@ def test_cpp_sequenced_ss2d_branch_is_the_python_route_bit_for_bit(layout, monke
     assert set(g1) == set(g0) and len(g0) == 11
     for k in g0:
         assert torch.equal(g1[k], g0[k]), k
+
+
+@pytest.mark.parametrize("hw", [(8, 8), (24, 28)])
+def test_cpp_sequenced_conv_branch_is_the_python_route_bit_for_bit(hw, monkeypatch):
+    """csrc_host conv_branch_fwd / _bwd against modules._conv_branch (BNReluFn, ConvBiasFn, PointwiseConvFn node by node): block
+    output, input gradient, every parameter gradient, the BatchNorm running statistics and step counters are identical bits
+    (planes of 64 positions take the one-kernel BatchNorm with the folded bias gradient, 672 positions the two-kernel form)."""
+    from medmamba_amd import _host, modules, ops
+    assert _host.module() is not None
+    torch.manual_seed(8)
+    blk = modules.SS_Conv_SSM(hidden_dim=128, drop_path=0.0, norm_layer=torch.nn.LayerNorm).to(DEV).train()
+    state0 = {k: v.clone() for k, v in blk.state_dict().items()}
+    x = torch.randn(4, hw[0], hw[1], 128, device=DEV, requires_grad=True)
+    g = torch.randn(4, hw[0], hw[1], 128, device=DEV)
+    calls = []
+    real = ops.ConvBranchFn.apply
+    monkeypatch.setattr(ops.ConvBranchFn, "apply", lambda *a: (calls.append(1), real(*a))[1])
+
+    def run(native):
+        blk.load_state_dict(state0)
+        if not native:
+            monkeypatch.setattr(ops, "conv_branch_native", lambda *a: None)
+        outs = []
+        for _ in range(2):                 # two passes: running statistics accumulate, the second pass overlaps the two streams
+            blk.zero_grad(set_to_none=True)
+            x.grad = None
+            out = blk(x)
+            out.backward(g)
+            outs.append((out.detach().clone(), x.grad.clone(), {k: p.grad.clone() for k, p in blk.named_parameters()}))
+        torch.cuda.synchronize()
+        return outs, {k: v.clone() for k, v in blk.state_dict().items() if "running" in k or "num_batches" in k}
+
+    r1, b1 = run(True)
+    assert calls == [1, 1]
+    r0, b0 = run(False)
+    assert calls == [1, 1]
+    for (o1, dx1, g1), (o0, dx0, g0) in zip(r1, r0):
+        assert torch.equal(o1, o0) and torch.equal(dx1, dx0)
+        for k in g0:
+            if k in ("conv33conv33conv11.1.weight", "conv33conv33conv11.4.weight"):
+                # MIOpen's weight-gradient kernels accumulate with atomics at some shapes: run-to-run noise in either route
+                assert torch.allclose(g1[k], g0[k], rtol=1e-4, atol=1e-4 * float(g0[k].abs().max())), k
+            else:
+                assert torch.equal(g1[k], g0[k]), k
+    assert len(b0) == 9
+    for k in b0:
+        assert torch.equal(b1[k], b0[k]), k
+    assert int(b1["conv33conv33conv11.0.num_batches_tracked"]) == int(state0["conv33conv33conv11.0.num_batches_tracked"]) + 2
