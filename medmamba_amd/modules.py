@@ -43,6 +43,7 @@ _OWN_BN = __import__("os").environ.get("MM_OWN_BN", "1") == "1"         # MM_OWN
 _GRAPH_BLOCK_MAX_L = int(__import__("os").environ.get("MM_GRAPH_BLOCK_MAX_L", "0"))
 _SIDE_STREAMS = {}
 _CONV_WARM = set()      # conv-branch input shapes whose MIOpen solver search has run (SS_Conv_SSM.forward)
+_CONV_COLD_RUNS = {}
 # images with at least this many positions start the side stream when the scan kernel is queued (see SS_Conv_SSM.forward)
 _LATE_SIDE_MIN_L = int(__import__("os").environ.get("MM_LATE_SIDE_MIN_L", "2048"))
 
@@ -595,9 +596,10 @@ class SS_Conv_SSM(nn.Module):
             x_cf = self.self_attention.forward_cf(right_n)                                   # (B, C/2, H*W)
             left = conv_body(left)                                                           # stays NCHW
             if cold:
-                if left.requires_grad:       # every forward of the first step precedes its first backward: warm from then on
-                    left.register_hook(lambda g, k=warm_key: _CONV_WARM.add(k))
-                else:
+                n = _CONV_COLD_RUNS[warm_key] = _CONV_COLD_RUNS.get(warm_key, 0) + 1
+                if left.requires_grad and n <= 64:     # every forward of the first step precedes its first backward: warm from
+                    left.register_hook(lambda g, k=warm_key: _CONV_WARM.add(k))        # then on (64: a caller that never
+                else:                                                                  # differentiates is not kept cold for ever)
                     _CONV_WARM.add(warm_key)
         # trailing ReLU + drop_path + permute back + cat + channel_shuffle(groups=2) + residual (MedMamba.py:347, 353-357)
         # fused in one HIP kernel
