@@ -365,6 +365,20 @@ int mm_gemm_f32(char opa, char opb, int m, int n, int k, float alpha, const floa
                 int ldb, int64_t stride_b, float beta, float* C, int ldc, int64_t stride_c, int batch, int32_t solution,
                 void* stream);
 
+/* AdamW update of the training step (train.py:187-201, 285-287: torch.optim.AdamW, amsgrad off) for a whole parameter list in one
+ * launch per mm_adamw_max_tensors() tensors.  Tensor i has numel[i] fp32 elements at params[i] / exp_avg[i] / exp_avg_sq[i]: these
+ * three pointer tables and numel live in DEVICE memory (built once).  The gradients are new tensors every step: grads_host is a HOST
+ * array with the gradient pointers of tensors t0 .. t0+nt-1, copied into the kernel arguments (nothing the next step could
+ * overwrite before the kernel has run).  The work is cut into chunks of mm_adamw_chunk() elements, one workgroup each: chunk c covers
+ * elements [chunk_index[c] * chunk, ...) of tensor chunk_tensor[c] (absolute index, within [t0, t0+nt)); device int32 tables of
+ * nchunks entries.  `step` = the step count AFTER this update (>= 1), the same for every tensor.  torch's rule and order:
+ *   p -= lr*wd*p;  m += (1-b1)*(g-m);  v = b2*v + (1-b2)*g*g;  p -= lr/(1-b1^step) * m / (sqrt(v)/sqrt(1-b2^step) + eps). */
+int mm_adamw_chunk(void);
+int mm_adamw_max_tensors(void);
+int mm_adamw_step(float* const* params, const float* const* grads_host, int t0, int nt, float* const* exp_avg, float* const* exp_avg_sq,
+                  const int64_t* numel, const int32_t* chunk_tensor, const int32_t* chunk_index, int nchunks, float lr, float beta1,
+                  float beta2, float eps, float weight_decay, double step, void* stream);
+
 /* hipEventRecord(event, stream) for host code that holds no HIP headers (the C++ sequencing layer brackets the scan kernels with
  * the caller's timing events). */
 int mm_event_record(void* event, void* stream);

@@ -99,6 +99,10 @@ SYMBOLS = {
                                                                               _f32p, ctypes.c_void_p]),
     "mm_ss2d_pack_parts_size": (ctypes.c_int, [ctypes.c_int] * 4),
     "mm_event_record": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "mm_adamw_chunk": (ctypes.c_int, []),
+    "mm_adamw_max_tensors": (ctypes.c_int, []),
+    "mm_adamw_step": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 5 + [ctypes.c_int]
+                      + [ctypes.c_float] * 5 + [ctypes.c_double, ctypes.c_void_p]),
     "mm_blas_attach": (ctypes.c_int, [ctypes.c_char_p]),
     "mm_blas_attached": (ctypes.c_int, []),
     "mm_blas_set_atomics": (ctypes.c_int, [ctypes.c_int]),
