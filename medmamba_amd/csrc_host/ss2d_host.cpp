@@ -70,7 +70,7 @@ inline void fill_common(mm_scan_args& a, const Tensor& u, const Tensor& delta, c
   a.delta_softplus = 1;
   a.u = fp(u); a.delta = fp(delta); a.A = fp(A); a.B = fp(Bm); a.C = fp(Cm); a.D = fp(Dp); a.delta_bias = fp(bias);
   a.u_sb = u.stride(0); a.u_sd = u.stride(1);
-  a.delta_sb = delta.stride(0); a.delta_sd = delta.stride(1);
+  if (delta.defined()) { a.delta_sb = delta.stride(0); a.delta_sd = delta.stride(1); }
   a.B_sb = Bm.stride(0); a.B_sg = Bm.stride(1); a.B_sn = Bm.stride(2);
   a.C_sb = Cm.stride(0); a.C_sg = Cm.stride(1); a.C_sn = Cm.stride(2);
   a.u_groups = 2; a.u_map = 0x1100u; a.rev_mask = 0b1010u;          // SS2D: 2 image orders, 4 directions (selective_scan_interface._CROSS_SHARED)
@@ -95,7 +95,8 @@ inline Tensor like_strided(const Tensor& dst, int64_t lead) {
 std::vector<Tensor> ss2d_fwd(const Tensor& x, const Tensor& in_w, const Tensor& conv_w, const c10::optional<Tensor>& conv_b_,
                              const Tensor& x_proj_w, const Tensor& dt_w, const Tensor& dt_b, const Tensor& A_logs, const Tensor& Ds,
                              const Tensor& ln_w, const Tensor& ln_b, const Tensor& out_w, int64_t H, int64_t W, double eps, bool cm,
-                             bool need_grad, int64_t variant, int64_t stream_, int64_t ev0, int64_t ev1, py::object prescan) {
+                             bool need_grad, int64_t variant, int64_t stream_, int64_t ev0, int64_t ev1, py::object prescan,
+                             bool fuse_dt) {
   void* stream = reinterpret_cast<void*>(stream_);
   const Tensor conv_b = conv_b_.has_value() ? *conv_b_ : Tensor();
   const int64_t Bsz = x.size(0), L = x.size(1), dm = x.size(2);
@@ -129,12 +130,20 @@ std::vector<Tensor> ss2d_fwd(const Tensor& x, const Tensor& in_w, const Tensor& 
     at::bmm_out(x_dbl, s.Wx.view({2, 2 * C, D}), u2m.view({2, D, Q}));                      // :259
     x_dbl = x_dbl.view({4, C, Q});
     xb = x_dbl.view({4, C, Bsz, L}).permute({2, 0, 1, 3});                                // (B, 4, C, L) view
-    delta = at::empty({4, D, Q}, o);
-    at::bmm_out(delta, s.Wdt, x_dbl.narrow(1, 0, R));                                     // :262
-    delta = delta.view({4 * D, Bsz, L}).permute({1, 0, 2});
   } else {
     x_dbl = at::matmul(s.Wx.view({1, 2, 2 * C, D}), u2.view({Bsz, 2, D, L})).view({Bsz, 4, C, L});
     xb = x_dbl;
+  }
+  // inference (nothing to differentiate) with a small dt rank: the dt projection (:262) runs inside the scan's staging phase — no
+  // (B, 4D, L) delta tensor is written or read, one GEMM less; training keeps the GEMM (the backward kernel consumes delta)
+  const Tensor dts = xb.narrow(2, 0, R);
+  fuse_dt = fuse_dt && !need_grad && R > 0 && R <= mm_scan_dt_max() && L % 4 == 0 && reinterpret_cast<uintptr_t>(dts.data_ptr()) % 16 == 0 &&
+            dts.stride(3) == 1 && dts.stride(0) % 4 == 0 && dts.stride(1) % 4 == 0 && dts.stride(2) % 4 == 0;
+  if (!fuse_dt && cm) {
+    delta = at::empty({4, D, Q}, o);
+    at::bmm_out(delta, s.Wdt, x_dbl.narrow(1, 0, R));                                     // :262
+    delta = delta.view({4 * D, Bsz, L}).permute({1, 0, 2});
+  } else if (!fuse_dt) {
     delta = at::matmul(s.Wdt.unsqueeze(0), x_dbl.narrow(2, 0, R)).view({Bsz, 4 * D, L});
   }
   if (!prescan.is_none()) prescan.attr("record")();       // the projections are queued; what follows is the latency-bound scan
@@ -146,6 +155,10 @@ std::vector<Tensor> ss2d_fwd(const Tensor& x, const Tensor& in_w, const Tensor& 
     mm_scan_args a = {};
     fill_common(a, u2, delta, s.A, xb.narrow(2, R, N), xb.narrow(2, R + N, N), s.Dp, s.bias);
     a.out = fpm(out4); a.x_chk = fpm(x_chk); a.variant = (int32_t)variant;
+    if (fuse_dt) {
+      a.dt_w = fp(s.Wdt); a.dts = fp(dts); a.dt_rank = (int32_t)R;
+      a.dts_sb = dts.stride(0); a.dts_sg = dts.stride(1); a.dts_sn = dts.stride(2);
+    }
     if (ev0) check(mm_event_record(reinterpret_cast<void*>(ev0), stream), "mm_event_record");
     check(mm_scan_fwd(&a, stream), "mm_scan_fwd");
     if (ev1) check(mm_event_record(reinterpret_cast<void*>(ev1), stream), "mm_event_record");

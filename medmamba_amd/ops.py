@@ -536,7 +536,7 @@ class SS2DBranchFn(torch.autograd.Function):
         with _lib.device_guard(x.device):
             ev0, ev1 = KERNEL_TIMER.pair("scan_fwd", scan_bytes_fwd(Bsz, 4 * D, L, N, 4), Bsz * 4 * D * L * N)
             res = _host.module().ss2d_fwd(x, in_w, conv_w, conv_b, x_proj_w, dt_w, dt_b, A_logs, Ds, ln_w, ln_b, out_w, H, W, float(eps),
-                                          cm, need_grad, _FWD_VARIANT, _stream(), ev0, ev1, prescan_event)
+                                          cm, need_grad, _FWD_VARIANT, _stream(), ev0, ev1, prescan_event, _FUSE_DT)
         if need_grad:
             ctx.save_for_backward(x, in_w, conv_w, conv_b, ln_w, ln_b, out_w, *res[1:])
             ctx.dims = (H, W, cm)
@@ -560,10 +560,10 @@ class SS2DBranchFn(torch.autograd.Function):
 
 def ss2d_branch_native_ok(x, mod_in_proj, mod_out_proj, conv, params):
     """True when SS2DBranchFn can take the whole branch: the extension is built, fp32 contiguous parameters, no biases on the two
-    projections (MedMamba.py:139, 181: bias=False by default), gradients wanted (inference keeps the route with the fused dt
-    projection)."""
+    projections (MedMamba.py:139, 181: bias=False by default).  Without gradients the same call runs the inference form (no
+    checkpoints, the dt projection inside the scan kernel)."""
     from . import _host
-    if _host.module() is None or not torch.is_grad_enabled() or not x.is_cuda or x.dtype != torch.float32:
+    if _host.module() is None or not x.is_cuda or x.dtype != torch.float32:
         return False
     if mod_in_proj.bias is not None or mod_out_proj.bias is not None:
         return False
