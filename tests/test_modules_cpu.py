@@ -180,3 +180,24 @@ def test_hooks_on_submodules_fire_and_do_not_change_results(oracle_scan):
         assert torch.allclose(p.grad, g0[k], rtol=1e-3, atol=1e-5), k
     h1.remove(); h2.remove()
     assert not M._has_hooks(blk)
+
+
+def test_hook_check_sees_hooks_registered_after_the_first_call_and_new_submodules():
+    """_has_hooks caches the sub-module list of a block (it runs twice per block and forward); hooks registered later are still
+    seen (the hook dictionaries are read every time), and so is a hook on a sub-module added after the list was cached."""
+    blk = M.SS_Conv_SSM(hidden_dim=16, drop_path=0.0, norm_layer=torch.nn.LayerNorm)
+    assert not M._has_hooks(blk) and "_mm_submodules" in blk.__dict__
+    h = blk.self_attention.in_proj.register_forward_pre_hook(lambda m, i: None)
+    assert M._has_hooks(blk)
+    h.remove()
+    assert not M._has_hooks(blk)
+    extra = torch.nn.Identity()
+    blk.add_module("probe", extra)
+    assert not M._has_hooks(blk)
+    h = extra.register_forward_hook(lambda m, i, o: None)
+    assert M._has_hooks(blk)
+    h.remove()
+    import copy
+    twin = copy.deepcopy(blk)
+    h = twin.ln_1.register_forward_hook(lambda m, i, o: None)
+    assert M._has_hooks(twin) and not M._has_hooks(blk)

@@ -28,4 +28,8 @@ run pmcW 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $o
 python3 tools/traffic_from_pmc.py $out/pmcF $out/pmcW $out/scan_traffic.json > /dev/null
 python3 tools/pmc_summary.py $out/pmcF $out/pmcW > $out/scan_traffic_pmc.txt
 rm -rf $out/pmcF $out/pmcW
+run host_ops_b64 300 python3 tools/host_op_profile.py 64
+run host_ops_b8 300 python3 tools/host_op_profile.py 8
+run adamw_S 120 python3 tools/bench_adamw.py S
+run adamw_B 120 python3 tools/bench_adamw.py B
 ls -la $out
