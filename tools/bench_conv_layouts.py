@@ -12,7 +12,10 @@ def t(fn, it=10):
     for _ in range(it): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / it * 1e3
-for h, hw in [(48, 56), (96, 28), (192, 14), (384, 7)]:
+import sys
+SHAPES = {"S": (64, [(48, 56), (96, 28), (192, 14), (384, 7)]), "B": (32, [(64, 96), (128, 48), (256, 24), (512, 12)])}
+B, shapes = SHAPES[sys.argv[1] if len(sys.argv) > 1 else "S"]
+for h, hw in shapes:
     res = []
     for fmt in (torch.contiguous_format, torch.channels_last):
         w = (torch.randn(h, h, 3, 3, device=dev) / (3 * h ** 0.5)).contiguous(memory_format=fmt).requires_grad_()
