@@ -161,6 +161,25 @@ def test_gemm_entry_refuses_without_an_attached_blas():
     assert blas._operand(torch.zeros(6, 10)[:, ::2]) == (None, 0)
 
 
+def test_host_side_helpers_validate_their_arguments_without_launching():
+    """mm_adamw_step / mm_event_record (ABI 20): NULL tables, empty or oversized tensor groups and a step count below 1 are refused
+    before anything touches the device."""
+    lib = _lib.lib()
+    assert lib.mm_adamw_chunk() >= 256 and lib.mm_adamw_max_tensors() * 8 < 4096       # the gradient pointers fit the kernel arguments
+    ok = 64                                                                              # any non-NULL value for a table pointer
+    arr = (ctypes.c_void_p * 2)(ok, ok)
+    args = lambda **kw: [kw.get("P", ok), kw.get("G", arr), kw.get("t0", 0), kw.get("nt", 2), ok, ok, ok, ok, ok, kw.get("nchunks", 2),
+                         1e-3, 0.9, 0.999, 1e-8, 1e-2, kw.get("step", 1.0), None]
+    assert lib.mm_adamw_step(*args(P=None)) == -1
+    assert lib.mm_adamw_step(*args(G=None)) == -1
+    assert lib.mm_adamw_step(*args(nchunks=0)) == -2
+    assert lib.mm_adamw_step(*args(nt=0)) == -2
+    assert lib.mm_adamw_step(*args(nt=lib.mm_adamw_max_tensors() + 1)) == -2
+    assert lib.mm_adamw_step(*args(step=0.0)) == -2
+    assert lib.mm_adamw_step(*args(G=(ctypes.c_void_p * 2)(ok, None))) == -1             # a NULL gradient pointer in the group
+    assert lib.mm_event_record(None, None) == -1
+
+
 def test_operator_has_no_cpu_fallback_and_mirrors_reference_errors():
     u = torch.zeros(1, 8, 8); A = torch.zeros(8, 16); B = torch.zeros(1, 4, 16, 8)
     with pytest.raises(RuntimeError, match="HIP device"):
