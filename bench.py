@@ -35,6 +35,10 @@ import os
 import sys
 import time
 
+# this pool's host driver supports only dmabuf IPC: without this RCCL / cross-process HIP memory sharing fails with
+# "hipIpcGetMemHandle: invalid argument".  Already exported on the boxes; kept as a default for any other launcher.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import torch
 import torch.distributed as dist
 import torch.nn as nn

@@ -32,6 +32,7 @@ def init_distributed(backend=None):
     if world == 1 or dist.is_initialized():
         return world
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC (see bench.py); read when RCCL first shares memory
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
     if backend == "nccl":
