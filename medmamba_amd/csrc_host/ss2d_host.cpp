@@ -13,6 +13,7 @@
 // No device code and no HIP headers here: the stream is handed over as an integer, device memory as at::Tensor.
 #include <torch/extension.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "medmamba_hip.h"
