@@ -644,3 +644,31 @@ def test_cpp_sequenced_conv_branch_is_the_python_route_bit_for_bit(hw, monkeypat
     for k in b0:
         assert torch.equal(b1[k], b0[k]), k
     assert int(b1["conv33conv33conv11.0.num_batches_tracked"]) == int(state0["conv33conv33conv11.0.num_batches_tracked"]) + 2
+
+
+def test_eval_mode_with_gradients_takes_the_same_values_on_both_routes(monkeypatch):
+    """Saliency-style use (test.py:101-108 without hooks): eval() but gradients w.r.t. the input wanted.  The SS2D branch then runs
+    the C++-sequenced training form (checkpoints, no fused dt projection), the conv branch its module chain with running
+    statistics; logits and input gradient agree with the all-Python route."""
+    from medmamba_amd import modules, ops
+    torch.manual_seed(12)
+    net = modules.VSSM(num_classes=4, depths=[1, 1, 1, 1], dims=[16, 32, 64, 128], drop_path_rate=0.0).to(DEV).eval()
+    x = torch.randn(2, 3, 64, 64, device=DEV, requires_grad=True)
+
+    def run():
+        x.grad = None
+        logits = net(x)
+        logits[:, 1].sum().backward()
+        return logits.detach().clone(), x.grad.clone()
+
+    calls = []
+    real = ops.SS2DBranchFn.apply
+    monkeypatch.setattr(ops.SS2DBranchFn, "apply", lambda *a: (calls.append(1), real(*a))[1])
+    l1, g1 = run()
+    assert len(calls) == 4
+    monkeypatch.setattr(ops, "ss2d_branch_native_ok", lambda *a: False)
+    l0, g0 = run()
+    assert len(calls) == 4
+    assert torch.allclose(l1, l0, rtol=1e-5, atol=1e-6)
+    assert float((g1 - g0).abs().max()) <= 1e-4 * max(1e-6, float(g0.abs().max()))
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
