@@ -1019,6 +1019,8 @@ inline LnPlan plan_ln(int batch, int D, int L, bool bwd) {
   return pl;
 }
 
+inline bool ln_flat() { static const bool on = [] { const char* e = getenv("MM_LN_FLAT"); return e ? atoi(e) != 0 : true; }(); return on; }   // A/B switch
+
 #define MM_LN_ARGS_F m, m_sb, m_sd, z, z_sb, z_sd, gamma, beta, eps, y, y_sb, y_sd, mu, rstd, D, L, npb
 int launch_ln_fwdc(const LnPlan& pl, dim3 grid, hipStream_t s, const float* m, int64_t m_sb, int64_t m_sd, const float* z,
                    int64_t z_sb, int64_t z_sd, const float* gamma, const float* beta, float eps, float* y, int64_t y_sb, int64_t y_sd,
@@ -1195,7 +1197,15 @@ int mm_ln_gate_fwd(const float* m, int64_t m_sb, int64_t m_sd, const float* z, i
   const int pw = pl.pw, npb = (L + pl.ppb - 1) / pl.ppb;
   const dim3 grid(batch * npb), blk(256);
   hipStream_t s = (hipStream_t)stream;
-  if (pl.nw > 0) return launch_ln_fwdc(pl, grid, s, m, m_sb, m_sd, z, z_sb, z_sd, gamma, beta, eps, y, y_sb, y_sd, mu, rstd, D, L, npb);
+  if (pl.nw > 0) {
+    // channel-major planes (batch stride = L everywhere): the positions of ALL batch items are one contiguous, 128-B aligned row of
+    // batch*L floats per channel.  Tiled per item, a 16-position run starts at byte 4*(b*L + 16*k) — at L = 196 / 49 three out of
+    // four straddle a 64-B sector, and every item ends in a ragged tile.  Tile the flattened row instead (same grid: the
+    // workgroups beyond ceil(batch*L / positions per workgroup) find no position and write nothing).
+    if (batch > 1 && m_sb == L && z_sb == L && y_sb == L && ln_flat())
+      return launch_ln_fwdc(pl, grid, s, m, m_sb, m_sd, z, z_sb, z_sd, gamma, beta, eps, y, y_sb, y_sd, mu, rstd, D, batch * L, (int)grid.x);
+    return launch_ln_fwdc(pl, grid, s, m, m_sb, m_sd, z, z_sb, z_sd, gamma, beta, eps, y, y_sb, y_sd, mu, rstd, D, L, npb);
+  }
   if (pl.cpl > 0) {
     return pw == 16 ? launch_ln_fwd1<16>(pl.cpl, grid, s, m, m_sb, m_sd, z, z_sb, z_sd, gamma, beta, eps, y, y_sb, y_sd, mu, rstd, D, L, npb)
                     : launch_ln_fwd1<4>(pl.cpl, grid, s, m, m_sb, m_sd, z, z_sb, z_sd, gamma, beta, eps, y, y_sb, y_sd, mu, rstd, D, L, npb);
@@ -1216,8 +1226,13 @@ int mm_ln_gate_bwd(const float* dy, int64_t dy_sb, int64_t dy_sd, const float* m
   const int pw = pl.pw, npb = (L + pl.ppb - 1) / pl.ppb;
   const dim3 grid(batch * npb), blk(256);
   hipStream_t s = (hipStream_t)stream;
-  if (pl.nw > 0)
+  if (pl.nw > 0) {
+    // flattened position row for channel-major planes (see mm_ln_gate_fwd); the grid — and with it the number of partial rows in
+    // ws, mm_ln_gate_rows — is unchanged: surplus workgroups contribute zero rows
+    if (batch > 1 && dy_sb == L && m_sb == L && z_sb == L && dm_sb == L && dz_sb == L && ln_flat())
+      return launch_ln_bwdc(pl, grid, s, dy, dy_sb, dy_sd, m, m_sb, m_sd, z, z_sb, z_sd, gamma, beta, mu, rstd, dm, dm_sb, dm_sd, dz, dz_sb, dz_sd, ws, D, batch * L, (int)grid.x);
     return launch_ln_bwdc(pl, grid, s, dy, dy_sb, dy_sd, m, m_sb, m_sd, z, z_sb, z_sd, gamma, beta, mu, rstd, dm, dm_sb, dm_sd, dz, dz_sb, dz_sd, ws, D, L, npb);
+  }
   if (pl.cpl > 0) {
     return pw == 16 ? launch_ln_bwd1<16>(pl.cpl, grid, s, dy, dy_sb, dy_sd, m, m_sb, m_sd, z, z_sb, z_sd, gamma, beta, mu, rstd, dm, dm_sb, dm_sd, dz, dz_sb, dz_sd, ws, D, L, npb)
                     : launch_ln_bwd1<4>(pl.cpl, grid, s, dy, dy_sb, dy_sd, m, m_sb, m_sd, z, z_sb, z_sd, gamma, beta, mu, rstd, dm, dm_sb, dm_sd, dz, dz_sb, dz_sd, ws, D, L, npb);
