@@ -983,10 +983,12 @@ inline LnPlan plan_ln(int batch, int D, int L, bool bwd) {
     const int lpp = (D + 15) / 16 <= cap ? 16 : 32;
     const int need = (D + lpp - 1) / lpp;
     if (need <= cap) {
-      // forward with 16 lanes per position: 32 positions per workgroup (128-B runs, 8 waves) — measured (tools/bench_ln_gate.py,
-      // B = 64, us): D = 192 31.6 -> 28.0, D = 384 24.8 -> 20.3; the backward does not gain (61.4 -> 64.9, 55.8 -> 53.9)
+      // 16 lanes per position: 32 positions per workgroup (128-B runs, 8 waves) — measured (tools/bench_ln_gate.py, B = 64, us):
+      // forward D = 192 31.6 -> 28.0, D = 384 24.8 -> 20.3; the backward did not gain while its tiles were cut per batch item
+      // (61.4 -> 64.9, 55.8 -> 53.9) and does since the channel-major row is tiled as a whole (mm_ln_gate_bwd): D = 384 46.7 ->
+      // 41.7, D = 192 56.4 -> 55.3 — and it leaves half as many partial rows to sum
       static const int pw32 = [] { const char* e = getenv("MM_LN_PW32"); return e ? atoi(e) : 1; }();
-      const bool wide = pw32 && lpp == 16 && !bwd;
+      const bool wide = lpp == 16 && (bwd ? pw32 != 3 && pw32 != 0 : pw32 != 0);   // MM_LN_PW32: 0 = never, 3 = forward only (A/B)
       pl.pw = wide ? 32 : 16; pl.nw = wide ? 8 : lpp / 4; pl.ppb = pl.pw;
       pl.cpl = need <= 16 ? 16 : need <= 24 ? 24 : need <= 32 ? 32 : 48;
       return pl;
