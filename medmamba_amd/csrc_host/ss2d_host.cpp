@@ -383,6 +383,25 @@ inline std::vector<Tensor> bn_bwd(const Tensor& dy_, const Tensor& x, const Tens
 
 const int64_t kOne2[2] = {1, 1}, kZero2[2] = {0, 0};
 
+// Backward of a dense 3x3 convolution (padding 1): {d input, d weight}.  Normally one at::convolution_backward (MIOpen: Winograd
+// data gradient + an implicit-GEMM weight gradient that accumulates with atomics).  With torch.backends.cudnn.deterministic set
+// (the reference's set_seed does, train.py:28-29) MIOpen answers the weight gradient with its per-image im2col + GEMM solver:
+// 640 extra launches and +17.5 ms per MedMamba-S step.  The same arithmetic as ONE im2col and ONE batched GEMM summed over the
+// batch in a fixed order (mm_im2col3x3: ATen's im2col launches once per image) is deterministic too and costs far less; the data gradient stays MIOpen's (Winograd, no atomics).
+std::pair<Tensor, Tensor> conv3x3_bwd(const Tensor& dy, const Tensor& x, const Tensor& w, void* stream) {
+  const at::IntArrayRef one(kOne2, 2), zero(kZero2, 2);
+  if (!at::globalContext().deterministicCuDNN()) {
+    auto r = at::convolution_backward(dy, x, w, c10::nullopt, one, one, one, false, zero, 1, {true, true, false});
+    return {std::get<0>(r), std::get<1>(r)};
+  }
+  auto r = at::convolution_backward(dy, x, w, c10::nullopt, one, one, one, false, zero, 1, {true, false, false});
+  const int64_t B = x.size(0), K = w.size(0), HW = x.size(2) * x.size(3);
+  Tensor cols = at::empty({B, 9 * x.size(1), HW}, x.options());                           // (B, 9C, HW) = F.unfold(x, 3, padding=1)
+  check(mm_im2col3x3(fp(x), fpm(cols), (int)B, (int)x.size(1), (int)x.size(2), (int)x.size(3), stream), "mm_im2col3x3");
+  Tensor dw = at::bmm(dy.reshape({B, K, HW}), cols.transpose(1, 2)).sum(0).view(w.sizes());
+  return {std::get<0>(r), dw};
+}
+
 // returns {out (B, K, H, W), y1, s1, c1, y2, s2, c2, y3, s3}
 std::vector<Tensor> conv_branch_fwd(const Tensor& x, const std::vector<Tensor>& bn1, const Tensor& w1, const Tensor& cb1,
                                     const std::vector<Tensor>& bn2, const Tensor& w2, const Tensor& cb2, const std::vector<Tensor>& bn3,
@@ -410,18 +429,17 @@ std::vector<Tensor> conv_branch_bwd(const Tensor& dout, const Tensor& x, const T
                                     const Tensor& s2, const Tensor& c2, const Tensor& y3, const Tensor& s3, int64_t stream_) {
   void* stream = reinterpret_cast<void*>(stream_);
   const int64_t B = x.size(0), H = x.size(2), W = x.size(3), C = y3.size(1), K = w3.size(0);
-  const at::IntArrayRef one(kOne2, 2), zero(kZero2, 2);
   const Tensor dy = dout.contiguous().view({B, K, H * W});
   const Tensor w3v = w3.view({K, C}), y3v = y3.view({B, C, H * W});
   Tensor dy3 = at::empty({B, C, H * W}, x.options());
   at::bmm_out(dy3, w3v.t().unsqueeze(0).expand({B, -1, -1}), dy);
   Tensor dw3 = at::bmm(dy, y3v.transpose(1, 2)).sum(0).view(w3.sizes());
   auto r3 = bn_bwd(dy3.view({B, C, H, W}), c2, g3, b3, s3, true, true, stream);
-  auto cbw2 = at::convolution_backward(r3[0], y2, w2, c10::nullopt, one, one, one, false, zero, 1, {true, true, false});
-  auto r2 = bn_bwd(std::get<0>(cbw2), c1, g2, b2, s2, true, true, stream);
-  auto cbw1 = at::convolution_backward(r2[0], y1, w1, c10::nullopt, one, one, one, false, zero, 1, {true, true, false});
-  auto r1 = bn_bwd(std::get<0>(cbw1), x, g1, b1, s1, false, false, stream);
-  return {r1[0], r1[1], r1[2], std::get<1>(cbw1), r2[3], r2[1], r2[2], std::get<1>(cbw2), r3[3], r3[1], r3[2], dw3};
+  auto cbw2 = conv3x3_bwd(r3[0], y2, w2, stream);
+  auto r2 = bn_bwd(cbw2.first, c1, g2, b2, s2, true, true, stream);
+  auto cbw1 = conv3x3_bwd(r2[0], y1, w1, stream);
+  auto r1 = bn_bwd(cbw1.first, x, g1, b1, s1, false, false, stream);
+  return {r1[0], r1[1], r1[2], cbw1.second, r2[3], r2[1], r2[2], cbw2.second, r3[3], r3[1], r3[2], dw3};
 }
 
 }  // namespace

@@ -652,8 +652,22 @@ class ConvBiasFn(torch.autograd.Function):
         x, w = ctx.saved_tensors
         stride, padding, dilation, has_bias = ctx.cfg
         dy = dy.contiguous()
-        dx, dw, _ = torch.ops.aten.convolution_backward(dy, x, w, None, stride, padding, dilation, False, [0, 0], 1,
-                                                        [ctx.needs_input_grad[0], ctx.needs_input_grad[1], False])
+        if (torch.backends.cudnn.deterministic and ctx.needs_input_grad[1] and x.is_cuda and tuple(w.shape[2:]) == (3, 3)
+                and stride == [1, 1] and padding == [1, 1] and dilation == [1, 1]):
+            # deterministic mode (the reference's set_seed, train.py:28-29): MIOpen's reproducible weight gradient is a per-image
+            # im2col + GEMM (640 launches, +17.5 ms per MedMamba-S step); one im2col + one batched GEMM + an ordered sum over the
+            # batch is the same arithmetic, reproducible, at a third of the cost (csrc_host conv3x3_bwd is the same code)
+            dx = torch.ops.aten.convolution_backward(dy, x, w, None, stride, padding, dilation, False, [0, 0], 1,
+                                                     [True, False, False])[0] if ctx.needs_input_grad[0] else None
+            B, K = dy.shape[0], dy.shape[1]
+            cols = torch.empty((B, 9 * x.shape[1], x.shape[2] * x.shape[3]), device=x.device, dtype=torch.float32)   # = F.unfold(x, 3, padding=1),
+            with _lib.device_guard(x.device):                                          # all images in one launch
+                _lib.check(_lib.lib().mm_im2col3x3(x.data_ptr(), cols.data_ptr(), B, x.shape[1], x.shape[2], x.shape[3], _stream()),
+                           "mm_im2col3x3")
+            dw = torch.bmm(dy.reshape(B, K, -1), cols.transpose(1, 2)).sum(0).view(w.shape)
+        else:
+            dx, dw, _ = torch.ops.aten.convolution_backward(dy, x, w, None, stride, padding, dilation, False, [0, 0], 1,
+                                                            [ctx.needs_input_grad[0], ctx.needs_input_grad[1], False])
         db = _bias_grad(dy) if (has_bias and ctx.needs_input_grad[2]) else None
         return dx, dw, db, None, None, None, None
 

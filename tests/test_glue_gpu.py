@@ -617,3 +617,14 @@ def test_own_conv_branch_matches_miopen_branch(monkeypatch):
         assert float((res[True][2][k] - v).abs().max()) <= 2e-4 * max(1e-3, float(v.abs().max())), k
     for k, v in res[False][3].items():
         assert float((res[True][3][k] - v).abs().max()) <= 1e-5 * max(1.0, float(v.abs().max())), k
+
+
+@pytest.mark.parametrize("shape", [(3, 5, 7, 9), (2, 48, 56, 56), (4, 16, 1, 1), (1, 3, 2, 300)])
+def test_im2col3x3_is_unfold(shape):
+    """mm_im2col3x3 (every image in one launch) == torch.nn.functional.unfold(x, 3, padding=1) bit for bit."""
+    from medmamba_amd import _lib
+    B, C, H, W = shape
+    x = torch.randn(*shape, device=DEV)
+    cols = torch.full((B, 9 * C, H * W), float("nan"), device=DEV)
+    _lib.check(_lib.lib().mm_im2col3x3(x.data_ptr(), cols.data_ptr(), B, C, H, W, _lib.raw_stream()), "mm_im2col3x3")
+    assert torch.equal(cols, torch.nn.functional.unfold(x, 3, padding=1))

@@ -672,3 +672,36 @@ def test_eval_mode_with_gradients_takes_the_same_values_on_both_routes(monkeypat
     assert torch.allclose(l1, l0, rtol=1e-5, atol=1e-6)
     assert float((g1 - g0).abs().max()) <= 1e-4 * max(1e-6, float(g0.abs().max()))
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
+
+
+def test_deterministic_mode_weight_gradient_of_the_dense_convs(monkeypatch):
+    """torch.backends.cudnn.deterministic (the reference's set_seed, train.py:28-29): the 3x3 convs' weight gradient is one im2col +
+    one batched GEMM + an ordered sum over the batch instead of MIOpen's per-image solver — the same values as MIOpen's default
+    weight gradient, identical bits run after run, on the C++-sequenced route and on the Python route."""
+    from medmamba_amd import modules, ops
+    torch.manual_seed(9)
+    blk = modules.SS_Conv_SSM(hidden_dim=96, drop_path=0.0, norm_layer=torch.nn.LayerNorm).to(DEV).train()
+    state0 = {k: v.clone() for k, v in blk.state_dict().items()}
+    x = torch.randn(8, 28, 28, 96, device=DEV, requires_grad=True)
+    g = torch.randn(8, 28, 28, 96, device=DEV)
+
+    def run():
+        blk.load_state_dict(state0)
+        blk.zero_grad(set_to_none=True)
+        x.grad = None
+        blk(x).backward(g)
+        return x.grad.clone(), {k: p.grad.clone() for k, p in blk.named_parameters()}
+
+    run()                                             # first pass over the shapes (solver search)
+    dx0, g0 = run()                                   # MIOpen's default weight gradient
+    monkeypatch.setattr(torch.backends.cudnn, "deterministic", True)
+    dx1, g1 = run()
+    dx2, g2 = run()
+    monkeypatch.setattr(ops, "conv_branch_native", lambda *a: None)
+    dx3, g3 = run()
+    assert torch.equal(dx1, dx2) and torch.equal(dx1, dx3)
+    for k in g1:
+        assert torch.equal(g1[k], g2[k]), k           # run to run
+        assert torch.equal(g1[k], g3[k]), k           # C++ route vs Python route
+        scale = max(1e-4, float(g0[k].abs().max()))
+        assert float((g1[k] - g0[k]).abs().max()) <= 2e-4 * scale, k
