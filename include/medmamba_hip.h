@@ -368,8 +368,10 @@ int mm_gemm_f32(char opa, char opb, int m, int n, int k, float alpha, const floa
 /* im2col of the input of a 3x3 / padding 1 / stride 1 convolution, every image in one launch: cols (batch, 9*C, H*W) with
  * cols[b][c*9 + r*3 + s][h*W + w] = x[b][c][h+r-1][w+s-1] (0 outside) — torch.nn.functional.unfold(x, 3, padding=1).  Used for the
  * reproducible weight gradient of the conv branch's dense convolutions (MedMamba.py:339, 342) under
- * torch.backends.cudnn.deterministic: dW = sum over b (fixed order) of dy[b] (K x HW) . cols[b]^T. */
-int mm_im2col3x3(const float* x, float* cols, int batch, int C, int H, int W, void* stream);
+ * torch.backends.cudnn.deterministic: dW = sum over b (fixed order) of dy[b] (K x HW) . cols[b]^T.
+ * group = gs > 1 (batch % gs == 0): the gs images of a group side by side, cols (batch/gs, 9*C, gs*H*W) with image b in columns
+ * [(b % gs)*H*W, ...) of group b / gs: one GEMM per group contracts over gs images (dy regrouped the same way). */
+int mm_im2col3x3(const float* x, float* cols, int batch, int C, int H, int W, int group, void* stream);
 
 /* AdamW update of the training step (train.py:187-201, 285-287: torch.optim.AdamW, amsgrad off) for a whole parameter list in one
  * launch per mm_adamw_max_tensors() tensors.  Tensor i has numel[i] fp32 elements at params[i] / exp_avg[i] / exp_avg_sq[i]: these

@@ -99,7 +99,7 @@ SYMBOLS = {
                                                                               _f32p, ctypes.c_void_p]),
     "mm_ss2d_pack_parts_size": (ctypes.c_int, [ctypes.c_int] * 4),
     "mm_event_record": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
-    "mm_im2col3x3": (ctypes.c_int, [_f32p, _f32p] + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
+    "mm_im2col3x3": (ctypes.c_int, [_f32p, _f32p] + [ctypes.c_int] * 5 + [ctypes.c_void_p]),
     "mm_adamw_chunk": (ctypes.c_int, []),
     "mm_adamw_max_tensors": (ctypes.c_int, []),
     "mm_adamw_step": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 5 + [ctypes.c_int]

@@ -395,10 +395,17 @@ std::pair<Tensor, Tensor> conv3x3_bwd(const Tensor& dy, const Tensor& x, const T
     return {std::get<0>(r), std::get<1>(r)};
   }
   auto r = at::convolution_backward(dy, x, w, c10::nullopt, one, one, one, false, zero, 1, {true, false, false});
-  const int64_t B = x.size(0), K = w.size(0), HW = x.size(2) * x.size(3);
-  Tensor cols = at::empty({B, 9 * x.size(1), HW}, x.options());                           // (B, 9C, HW) = F.unfold(x, 3, padding=1)
-  check(mm_im2col3x3(fp(x), fpm(cols), (int)B, (int)x.size(1), (int)x.size(2), (int)x.size(3), stream), "mm_im2col3x3");
-  Tensor dw = at::bmm(dy.reshape({B, K, HW}), cols.transpose(1, 2)).sum(0).view(w.sizes());
+  const int64_t B = x.size(0), C = x.size(1), K = w.size(0), HW = x.size(2) * x.size(3);
+  // gs images per GEMM: as many as still leave >= 512 output tiles for the chip (the partial products to sum shrink by gs:
+  // 340 MB -> 21 MB per conv at the 7x7 stage); gs = 1 is F.unfold's layout
+  const int64_t tiles = ((K + 63) / 64) * ((9 * C + 63) / 64);
+  int64_t gs = 1;
+  while (gs * 2 <= B && B % (gs * 2) == 0 && (B / (gs * 2)) * tiles >= 512) gs *= 2;
+  Tensor cols = at::empty({B / gs, 9 * C, gs * HW}, x.options());
+  check(mm_im2col3x3(fp(x), fpm(cols), (int)B, (int)C, (int)x.size(2), (int)x.size(3), (int)gs, stream), "mm_im2col3x3");
+  const Tensor dyg = gs == 1 ? dy.reshape({B, K, HW})
+                             : dy.reshape({B / gs, gs, K, HW}).transpose(1, 2).reshape({B / gs, K, gs * HW});   // one copy
+  Tensor dw = at::bmm(dyg, cols.transpose(1, 2)).sum(0).view(w.sizes());
   return {std::get<0>(r), dw};
 }
 

@@ -659,12 +659,16 @@ class ConvBiasFn(torch.autograd.Function):
             # batch is the same arithmetic, reproducible, at a third of the cost (csrc_host conv3x3_bwd is the same code)
             dx = torch.ops.aten.convolution_backward(dy, x, w, None, stride, padding, dilation, False, [0, 0], 1,
                                                      [True, False, False])[0] if ctx.needs_input_grad[0] else None
-            B, K = dy.shape[0], dy.shape[1]
-            cols = torch.empty((B, 9 * x.shape[1], x.shape[2] * x.shape[3]), device=x.device, dtype=torch.float32)   # = F.unfold(x, 3, padding=1),
+            B, K, C, HW = dy.shape[0], dy.shape[1], x.shape[1], x.shape[2] * x.shape[3]
+            tiles, gs = ((K + 63) // 64) * ((9 * C + 63) // 64), 1                     # images per GEMM (csrc_host conv3x3_bwd)
+            while gs * 2 <= B and B % (gs * 2) == 0 and (B // (gs * 2)) * tiles >= 512:
+                gs *= 2
+            cols = torch.empty((B // gs, 9 * C, gs * HW), device=x.device, dtype=torch.float32)   # gs = 1: F.unfold(x, 3, padding=1),
             with _lib.device_guard(x.device):                                          # all images in one launch
-                _lib.check(_lib.lib().mm_im2col3x3(x.data_ptr(), cols.data_ptr(), B, x.shape[1], x.shape[2], x.shape[3], _stream()),
+                _lib.check(_lib.lib().mm_im2col3x3(x.data_ptr(), cols.data_ptr(), B, C, x.shape[2], x.shape[3], gs, _stream()),
                            "mm_im2col3x3")
-            dw = torch.bmm(dy.reshape(B, K, -1), cols.transpose(1, 2)).sum(0).view(w.shape)
+            dyg = dy.reshape(B, K, HW) if gs == 1 else dy.reshape(B // gs, gs, K, HW).transpose(1, 2).reshape(B // gs, K, gs * HW)
+            dw = torch.bmm(dyg, cols.transpose(1, 2)).sum(0).view(w.shape)
         else:
             dx, dw, _ = torch.ops.aten.convolution_backward(dy, x, w, None, stride, padding, dilation, False, [0, 0], 1,
                                                             [ctx.needs_input_grad[0], ctx.needs_input_grad[1], False])

@@ -626,5 +626,13 @@ def test_im2col3x3_is_unfold(shape):
     B, C, H, W = shape
     x = torch.randn(*shape, device=DEV)
     cols = torch.full((B, 9 * C, H * W), float("nan"), device=DEV)
-    _lib.check(_lib.lib().mm_im2col3x3(x.data_ptr(), cols.data_ptr(), B, C, H, W, _lib.raw_stream()), "mm_im2col3x3")
-    assert torch.equal(cols, torch.nn.functional.unfold(x, 3, padding=1))
+    _lib.check(_lib.lib().mm_im2col3x3(x.data_ptr(), cols.data_ptr(), B, C, H, W, 1, _lib.raw_stream()), "mm_im2col3x3")
+    ref = torch.nn.functional.unfold(x, 3, padding=1)
+    assert torch.equal(cols, ref)
+    for gs in (2, 4):                        # gs images side by side: (B/gs, 9C, gs*HW)
+        if B % gs == 0:
+            grouped = torch.full((B // gs, 9 * C, gs * H * W), float("nan"), device=DEV)
+            _lib.check(_lib.lib().mm_im2col3x3(x.data_ptr(), grouped.data_ptr(), B, C, H, W, gs, _lib.raw_stream()), "mm_im2col3x3")
+            want = ref.view(B // gs, gs, 9 * C, H * W).transpose(1, 2).reshape(B // gs, 9 * C, gs * H * W)
+            assert torch.equal(grouped, want), gs
+    assert _lib.lib().mm_im2col3x3(x.data_ptr(), cols.data_ptr(), B, C, H, W, 0, None) == -2
