@@ -61,6 +61,9 @@ def main(argv=None):
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     T.set_seed(args.seed)
+    if os.environ.get("MM_TUNED_GEMMS", "1") == "1":
+        from medmamba_amd.tuning import enable_tuned_gemms
+        enable_tuned_gemms()        # recorded GEMM kernels for the shapes in the table (64 x 224^2 T/S, 32 x 384^2 B); others: heuristics
     os.makedirs(args.save_dir, exist_ok=True)
 
     if args.synthetic:
