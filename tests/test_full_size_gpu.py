@@ -52,7 +52,7 @@ def _compare_grads(g0, g1, what, l2_tol=3e-3, max_tol=2e-2):
             continue
         l2 = float((a - b).norm()) / den
         mx = float((a - b).abs().max()) / max(1e-6, float(a.abs().max()))
-        worst = max(worst, (l2, k))
+        worst = max(worst, (l2, k), key=lambda t: t[0])
         assert l2 <= l2_tol and mx <= max_tol, (what, k, l2, mx)
     return worst
 
