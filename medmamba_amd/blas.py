@@ -65,8 +65,7 @@ def any_shape(on):
 
 def load_table(path):
     """Read TunableOp's result file; keep the rocBLAS winners.  Returns the number of usable entries (0: nothing goes direct)."""
-    _TABLE.clear()
-    _STATE["file"] = None
+    clear()
     if not _ENABLED or not torch.cuda.is_available() or not os.path.exists(path):
         return 0
     rb = _rocblas_path()
@@ -88,7 +87,19 @@ def load_table(path):
         elif r[0].startswith("GemmTunableOp_float_"):
             _TABLE[(False, r[1])] = int(r[2][len("Gemm_Rocblas_"):])
     _STATE["file"] = path
+    from . import _host
+    if _host.module() is not None:          # the C++ sequencing layer issues its GEMMs the same way (csrc_host gemm_out)
+        _host.module().set_gemm_table([(("B" if batched else "N") + key, sol) for (batched, key), sol in _TABLE.items()])
     return len(_TABLE)
+
+
+def clear():
+    """Forget the table here and in the C++ sequencing layer: every GEMM goes through torch again."""
+    _TABLE.clear()
+    _STATE["file"] = None
+    from . import _host
+    if _host.module() is not None:
+        _host.module().set_gemm_table([])
 
 
 def _operand(t):

@@ -14,6 +14,8 @@
 #include <torch/extension.h>
 
 #include <algorithm>
+#include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "medmamba_hip.h"
@@ -49,6 +51,61 @@ inline Tensor cm2d(const Tensor& t_) {
 }
 
 inline Tensor rows(const Tensor& t) { return t.stride(-1) == 1 ? t : t.contiguous(); }
+
+// ---- GEMMs: rocBLAS directly (mm_gemm_f32, the recorded solution index) where TunableOp's table names a rocBLAS solution for
+// exactly this problem — 6 instead of 17-21 us of host time per call through ATen's dispatcher + TunableOp's string-keyed lookup +
+// library front end — ATen otherwise (hipBLASLt winners, unrecorded shapes, no table).  The key is the one medmamba_amd/blas.py
+// builds (TunableOp's own): column-major problem of out^T = b^T a^T.
+std::unordered_map<std::string, int32_t> g_gemm_table;      // filled once by blas.load_table (set_gemm_table), read-only afterwards
+
+inline bool col_operand(const Tensor& t, char& op, int64_t& ld) {
+  const int64_t s0 = t.stride(-2), s1 = t.stride(-1);
+  if (s1 == 1 && s0 >= t.size(-1)) { op = 'n'; ld = s0; return true; }
+  if (s0 == 1 && s1 >= t.size(-2)) { op = 't'; ld = s1; return true; }
+  return false;
+}
+
+// out = a @ b; a (m, k) or (B, m, k), b (k, n) or (B, k, n), out (m, n) or (B, m, n): a 2-D operand of a 3-D product is shared
+inline void gemm_out(Tensor& out, const Tensor& a, const Tensor& b, void* stream) {
+  if (!g_gemm_table.empty() && out.stride(-1) == 1) {
+    char opa, opb;
+    int64_t lda, ldb;
+    if (col_operand(b, opa, lda) && col_operand(a, opb, ldb)) {
+      const int64_t m = a.size(-2), k = a.size(-1), n = b.size(-1), ldc = out.stride(-2);
+      const bool batched = out.dim() == 3;
+      std::string key;
+      key.reserve(64);
+      key += batched ? 'B' : 'N'; key += opa; key += opb;
+      key += '_'; key += std::to_string(n); key += '_'; key += std::to_string(m); key += '_'; key += std::to_string(k);
+      if (batched) { key += "_B_"; key += std::to_string(out.size(0)); }
+      key += "_ld_"; key += std::to_string(lda); key += '_'; key += std::to_string(ldb); key += '_'; key += std::to_string(ldc);
+      const auto it = g_gemm_table.find(key);
+      if (it != g_gemm_table.end()) {
+        const int64_t sa = b.dim() == 3 ? b.stride(0) : 0, sb = a.dim() == 3 ? a.stride(0) : 0, sc = batched ? out.stride(0) : 0;
+        check(mm_gemm_f32((char)(opa - 32), (char)(opb - 32), (int)n, (int)m, (int)k, 1.0f, fp(b), (int)lda, sa, fp(a), (int)ldb, sb, 0.0f,
+                          fpm(out), (int)ldc, sc, batched ? (int)out.size(0) : 1, it->second, stream), "mm_gemm_f32");
+        return;
+      }
+    }
+  }
+  if (out.dim() == 3) {
+    const int64_t nb = out.size(0);
+    at::bmm_out(out, a.dim() == 3 ? a : a.unsqueeze(0).expand({nb, -1, -1}), b.dim() == 3 ? b : b.unsqueeze(0).expand({nb, -1, -1}));
+  } else {
+    at::mm_out(out, a, b);
+  }
+}
+
+inline Tensor gemm_new(const Tensor& a, const Tensor& b, void* stream) {      // batched product into a fresh (B, m, n) tensor
+  Tensor out = at::empty({a.dim() == 3 ? a.size(0) : b.size(0), a.size(-2), b.size(-1)}, a.options());
+  gemm_out(out, a, b, stream);
+  return out;
+}
+
+void set_gemm_table(const std::vector<std::pair<std::string, int64_t>>& entries) {
+  g_gemm_table.clear();
+  for (const auto& e : entries) g_gemm_table.emplace(e.first, (int32_t)e.second);
+}
 
 struct Seg { Tensor Wx, Wdt, A, Dp, bias; int64_t oA, oD, ob; };
 inline Seg segments(const Tensor& P, int64_t D, int64_t C, int64_t R, int64_t N) {
@@ -108,11 +165,11 @@ std::vector<Tensor> ss2d_fwd(const Tensor& x, const Tensor& in_w, const Tensor& 
   Tensor xz;
   if (cm) {
     xz = at::empty({2 * D, Q}, o);
-    at::mm_out(xz, in_w, x.view({Q, dm}).t());
+    gemm_out(xz, in_w, x.view({Q, dm}).t(), stream);
     xz = xz.view({2 * D, Bsz, L}).permute({1, 0, 2});
   } else {
     xz = at::empty({Bsz, 2 * D, L}, o);
-    at::bmm_out(xz, in_w.unsqueeze(0).expand({Bsz, -1, -1}), x.transpose(1, 2));
+    gemm_out(xz, in_w, x.transpose(1, 2), stream);
   }
   const Tensor x_cf = xz.narrow(1, 0, D), z_cf = xz.narrow(1, D, D);
   // depthwise conv3x3 + SiLU in both image orders (:294-295, :256)
@@ -128,7 +185,7 @@ std::vector<Tensor> ss2d_fwd(const Tensor& x, const Tensor& in_w, const Tensor& 
   if (cm) {
     const Tensor u2m = cm2d(u2);                                                          // (2D, Q) view
     x_dbl = at::empty({2, 2 * C, Q}, o);
-    at::bmm_out(x_dbl, s.Wx.view({2, 2 * C, D}), u2m.view({2, D, Q}));                      // :259
+    gemm_out(x_dbl, s.Wx.view({2, 2 * C, D}), u2m.view({2, D, Q}), stream);                 // :259
     x_dbl = x_dbl.view({4, C, Q});
     xb = x_dbl.view({4, C, Bsz, L}).permute({2, 0, 1, 3});                                // (B, 4, C, L) view
   } else {
@@ -142,7 +199,7 @@ std::vector<Tensor> ss2d_fwd(const Tensor& x, const Tensor& in_w, const Tensor& 
             dts.stride(3) == 1 && dts.stride(0) % 4 == 0 && dts.stride(1) % 4 == 0 && dts.stride(2) % 4 == 0;
   if (!fuse_dt && cm) {
     delta = at::empty({4, D, Q}, o);
-    at::bmm_out(delta, s.Wdt, x_dbl.narrow(1, 0, R));                                     // :262
+    gemm_out(delta, s.Wdt, x_dbl.narrow(1, 0, R), stream);                                // :262
     delta = delta.view({4 * D, Bsz, L}).permute({1, 0, 2});
   } else if (!fuse_dt) {
     delta = at::matmul(s.Wdt.unsqueeze(0), x_dbl.narrow(2, 0, R)).view({Bsz, 4 * D, L});
@@ -174,11 +231,11 @@ std::vector<Tensor> ss2d_fwd(const Tensor& x, const Tensor& in_w, const Tensor& 
   Tensor out;
   if (cm && Bsz > 1) {
     out = at::empty({out_w.size(0), Q}, o);
-    at::mm_out(out, out_w, cm2d(y));
+    gemm_out(out, out_w, cm2d(y), stream);
     out = out.view({-1, Bsz, L}).permute({1, 0, 2});
   } else {
     out = at::empty({Bsz, out_w.size(0), L}, o);
-    at::bmm_out(out, out_w.unsqueeze(0).expand({Bsz, -1, -1}), y);
+    gemm_out(out, out_w, y, stream);
   }
   if (!need_grad) return {out};
   return {out, xz, u2, x_dbl, delta, P, x_chk, m, mu, rstd, y};
@@ -206,15 +263,15 @@ std::vector<Tensor> ss2d_bwd(const Tensor& dout_, const Tensor& x, const Tensor&
   if (cm && Bsz > 1 && is_cm(dout_)) {
     const Tensor g2 = cm2d(dout_);                                                        // (d_model, Q)
     dy = at::empty({D, Q}, o);
-    at::mm_out(dy, out_w.t(), g2);
+    gemm_out(dy, out_w.t(), g2, stream);
     dy = dy.view({D, Bsz, L}).permute({1, 0, 2});
     d_out_w = at::empty({out_w.size(0), D}, o);
-    at::mm_out(d_out_w, g2, cm2d(y).t());
+    gemm_out(d_out_w, g2, cm2d(y).t(), stream);
   } else {
     const Tensor g = rows(dout_);
     dy = at::empty({Bsz, D, L}, o);
-    at::bmm_out(dy, out_w.t().unsqueeze(0).expand({Bsz, -1, -1}), g);
-    d_out_w = at::bmm(g, rows(y).transpose(1, 2)).sum(0);
+    gemm_out(dy, out_w.t(), g, stream);
+    d_out_w = gemm_new(g, rows(y).transpose(1, 2), stream).sum(0);
   }
   // out_norm + gate backward, its plane transpose for the column-major directions
   Tensor dout2 = planes(Bsz, 2 * D, L, o, cm);            // channel block 0: dm, block 1: its plane transpose
@@ -279,13 +336,13 @@ std::vector<Tensor> ss2d_bwd(const Tensor& dout_, const Tensor& x, const Tensor&
   if (cm) {
     const Tensor dd = ddelta.permute({1, 0, 2}).reshape({4, D, Q});                        // views of (4D, B, L) storage
     Tensor dWdt = ds.Wdt, dxr = dx_dbl.narrow(1, 0, R);
-    at::bmm_out(dWdt, dd, x_dbl.narrow(1, 0, R).transpose(1, 2));                          // (4, D, R)
-    at::bmm_out(dxr, s.Wdt.transpose(1, 2), dd);                                          // dt rows of d(x_dbl), in place
+    gemm_out(dWdt, dd, x_dbl.narrow(1, 0, R).transpose(1, 2), stream);                     // (4, D, R)
+    gemm_out(dxr, s.Wdt.transpose(1, 2), dd, stream);                                     // dt rows of d(x_dbl), in place
     const Tensor dx2 = dx_dbl.view({2, 2 * C, Q});
     Tensor du2m = at::empty({2, D, Q}, o);
-    at::bmm_out(du2m, s.Wx.view({2, 2 * C, D}).transpose(1, 2), dx2);                      // Wx^T d(x_dbl); pairs added later
+    gemm_out(du2m, s.Wx.view({2, 2 * C, D}).transpose(1, 2), dx2, stream);                 // Wx^T d(x_dbl); pairs added later
     Tensor dWx = ds.Wx.view({2, 2 * C, D});
-    at::bmm_out(dWx, dx2, cm2d(u2).view({2, D, Q}).transpose(1, 2));
+    gemm_out(dWx, dx2, cm2d(u2).view({2, D, Q}).transpose(1, 2), stream);
     du2 = du2m.view({2 * D, Bsz, L}).permute({1, 0, 2});
   } else {
     const Tensor dd = ddelta.view({Bsz, 4, D, L});
@@ -328,13 +385,13 @@ std::vector<Tensor> ss2d_bwd(const Tensor& dout_, const Tensor& x, const Tensor&
   if (cm && is_cm(dxz)) {
     const Tensor g2 = cm2d(dxz), x2 = x.view({Q, dm});
     dx = at::empty({Q, dm}, o);
-    at::mm_out(dx, g2.t(), in_w);
+    gemm_out(dx, g2.t(), in_w, stream);
     dx = dx.view({Bsz, L, dm});
-    at::mm_out(d_in_w, g2, x2);
+    gemm_out(d_in_w, g2, x2, stream);
   } else {
     dx = at::empty({Bsz, L, dm}, o);
-    at::bmm_out(dx, dxz.transpose(1, 2), in_w.unsqueeze(0).expand({Bsz, -1, -1}));
-    at::sum_out(d_in_w, at::bmm(dxz, x), DIM0);
+    gemm_out(dx, dxz.transpose(1, 2), in_w, stream);
+    at::sum_out(d_in_w, gemm_new(dxz, x, stream), DIM0);
   }
   return {dx, d_in_w, dcw, dcb, gs.Wx, gs.Wdt, gs.bias.view({4, D}), gs.A, gs.Dp, ln_out.narrow(0, 0, D), ln_out.narrow(0, D, D), d_out_w};
 }
@@ -425,7 +482,7 @@ std::vector<Tensor> conv_branch_fwd(const Tensor& x, const std::vector<Tensor>& 
   auto [y3, s3] = bn_fwd(c2, p3, true, cb2, stream);
   const int64_t B = x.size(0), C = y3.size(1), H = x.size(2), W = x.size(3), K = w3.size(0);
   Tensor out = at::empty({B, K, H * W}, x.options());
-  at::bmm_out(out, w3.view({K, C}).unsqueeze(0).expand({B, -1, -1}), y3.view({B, C, H * W}));
+  gemm_out(out, w3.view({K, C}), y3.view({B, C, H * W}), stream);
   return {out.view({B, K, H, W}), y1, s1, c1, y2, s2, c2, y3, s3};
 }
 
@@ -439,8 +496,8 @@ std::vector<Tensor> conv_branch_bwd(const Tensor& dout, const Tensor& x, const T
   const Tensor dy = dout.contiguous().view({B, K, H * W});
   const Tensor w3v = w3.view({K, C}), y3v = y3.view({B, C, H * W});
   Tensor dy3 = at::empty({B, C, H * W}, x.options());
-  at::bmm_out(dy3, w3v.t().unsqueeze(0).expand({B, -1, -1}), dy);
-  Tensor dw3 = at::bmm(dy, y3v.transpose(1, 2)).sum(0).view(w3.sizes());
+  gemm_out(dy3, w3v.t(), dy, stream);
+  Tensor dw3 = gemm_new(dy, y3v.transpose(1, 2), stream).sum(0).view(w3.sizes());
   auto r3 = bn_bwd(dy3.view({B, C, H, W}), c2, g3, b3, s3, true, true, stream);
   auto cbw2 = conv3x3_bwd(r3[0], y2, w2, stream);
   auto r2 = bn_bwd(cbw2.first, c1, g2, b2, s2, true, true, stream);
@@ -457,5 +514,6 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, mod) {
   mod.doc() = "medmamba_amd: C++ sequencing of the SS2D branch over the C ABI of libmedmamba_hip.so";
   mod.def("ss2d_fwd", &ss2d_fwd);
   mod.def("ss2d_bwd", &ss2d_bwd);
+  mod.def("set_gemm_table", &set_gemm_table);
   mod.def("abi_version", []() { return mm_abi_version(); });
 }

@@ -116,10 +116,21 @@ def test_recorded_solutions_are_used_at_full_size(monkeypatch):
         saved = dict(blas._TABLE)
         blas._TABLE.clear()
         try:
-            o0, dx0, g0 = run()
+            o0, dx0, g0 = run()                  # (the Python route is still patched in: its GEMMs go through torch now)
         finally:
             blas._TABLE.update(saved)
         assert n_direct >= 10, n_direct
+        # the C++-sequenced routes issue the same recorded rocBLAS solutions through mm_gemm_f32 themselves (csrc_host gemm_out):
+        # identical bits to the Python route with the same table
+        monkeypatch.undo()
+        from medmamba_amd import _host
+        assert _host.module() is not None
+        o2, dx2, g2 = run()
+        assert torch.equal(o2, o1) and torch.equal(dx2, dx1)
+        for k in g1:
+            if k in ("conv33conv33conv11.1.weight", "conv33conv33conv11.4.weight"):
+                continue          # MIOpen's weight-gradient kernels accumulate with atomics
+            assert torch.equal(g2[k], g1[k]), k
         assert torch.allclose(o1, o0, rtol=1e-4, atol=1e-4)
         assert (dx1 - dx0).abs().max().item() <= 2e-3 * dx0.abs().max().item()
         for k in g0:
@@ -128,4 +139,4 @@ def test_recorded_solutions_are_used_at_full_size(monkeypatch):
             assert (g1[k] - g0[k]).abs().max().item() <= 2e-3 * max(1e-4, g0[k].abs().max().item()), k
     finally:
         torch.cuda.tunable.enable(False)
-        blas._TABLE.clear()
+        blas.clear()
