@@ -354,9 +354,12 @@ int mm_channel_sum_nchw(const float* x, float* out, int batch, int C, int HW, vo
  *   C[i] = alpha * op(A[i]) * op(B[i]) + beta * C[i],  i < batch;  op = 'N' | 'T';  op(A) is m x k, op(B) k x n, C m x n;
  *   leading dimensions in elements, batch strides in elements (0 = the same matrix for every i);
  *   solution = a rocBLAS solution index recorded for exactly this problem (rocblas_gemm_algo_solution_index), 0 = the
- *   library's own choice.  One handle per host thread and device, bound to `stream` at every call; atomics follow
+ *   library's own choice.  One handle per host thread, device and stream (a handle's device workspace must not serve two
+ *   GEMMs that run at the same time on different streams); atomics follow
  *   mm_blas_set_atomics (default: allowed, rocBLAS's own default).
- * Returns MM_ERR_BLAS when nothing is attached or rocBLAS reports an error (mm_blas_last_status() holds its status). */
+ * Returns MM_ERR_BLAS when nothing is attached or rocBLAS reports an error (mm_blas_last_status() holds its status), and
+ * MM_ERR_UNSUPPORTED (nothing launched) for the FIRST call on a stream that is currently being captured into a hipGraph: the
+ * handle it would need allocates device memory. */
 int mm_blas_attach(const char* librocblas_path);
 int mm_blas_attached(void);
 int mm_blas_set_atomics(int allowed);

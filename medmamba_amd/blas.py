@@ -144,6 +144,8 @@ def gemm(out, a, b, beta=0.0):
         sol = 0
     rc = _lib.lib().mm_gemm_f32(opa.upper().encode(), opb.upper().encode(), n, m, k, 1.0, b.data_ptr(), lda, sa, a.data_ptr(), ldb, sb,
                                 beta, out.data_ptr(), ldc, sc, batch, sol, _lib.raw_stream())
+    if rc == -3:          # MM_ERR_UNSUPPORTED: first call on a stream that is being captured into a hipGraph — the caller uses torch
+        return False
     if rc != 0:
         raise _lib.MedMambaHipError(f"mm_gemm_f32 failed: status {rc}, rocBLAS status {_lib.lib().mm_blas_last_status()} for {key[1]}")
     STATS["direct"] += 1

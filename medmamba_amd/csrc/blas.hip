@@ -35,8 +35,17 @@ Blas g_blas;
 std::mutex g_mu;
 thread_local int t_last_status = 0;
 
-struct Handle { rb_handle h = nullptr; hipStream_t stream = (hipStream_t)-1; int epoch = -1; };
-thread_local std::unordered_map<int, Handle> t_handles;      // per host thread: device -> handle
+// One handle per host thread, device AND stream: a rocBLAS handle owns one device workspace, and two GEMMs that use it (split-K
+// reductions) must not run at the same time — which they do when a block's two branches issue GEMMs on two streams from one thread.
+struct Handle { rb_handle h = nullptr; int epoch = -1; };
+struct HandleKey {
+  int dev; hipStream_t stream;
+  bool operator==(const HandleKey& o) const { return dev == o.dev && stream == o.stream; }
+};
+struct HandleKeyHash {
+  size_t operator()(const HandleKey& k) const { return std::hash<const void*>()((const void*)k.stream) * 31u + (size_t)k.dev; }
+};
+thread_local std::unordered_map<HandleKey, Handle, HandleKeyHash> t_handles;
 
 }  // namespace
 
@@ -88,19 +97,24 @@ int mm_gemm_f32(char opa, char opb, int m, int n, int k, float alpha, const floa
   if (lda < (opa == 'N' ? m : k) || ldb < (opb == 'N' ? k : n) || ldc < m) return MM_ERR_SHAPE;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return MM_ERR_BLAS;
-  Handle& hd = t_handles[dev];
+  const HandleKey key{dev, (hipStream_t)stream};
+  if (t_handles.find(key) == t_handles.end()) {
+    // a new handle allocates its device workspace: not while `stream` is being captured into a hipGraph (the caller then issues
+    // this GEMM through its own BLAS; streams that carried a GEMM before the capture keep their handle and are fine)
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing((hipStream_t)stream, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
+    if (cs != hipStreamCaptureStatusNone) return MM_ERR_UNSUPPORTED;
+  }
+  Handle& hd = t_handles[key];
   if (!hd.h) {
     t_last_status = g_blas.create(&hd.h);
     if (t_last_status != 0) { hd.h = nullptr; return MM_ERR_BLAS; }
+    t_last_status = g_blas.set_stream(hd.h, (hipStream_t)stream);
+    if (t_last_status != 0) return MM_ERR_BLAS;
   }
   if (hd.epoch != g_blas.atomics_epoch) {
     if (g_blas.set_atomics) (void)g_blas.set_atomics(hd.h, g_blas.atomics);
     hd.epoch = g_blas.atomics_epoch;
-  }
-  if (hd.stream != (hipStream_t)stream) {
-    t_last_status = g_blas.set_stream(hd.h, (hipStream_t)stream);
-    if (t_last_status != 0) return MM_ERR_BLAS;
-    hd.stream = (hipStream_t)stream;
   }
   const int ta = opa == 'N' ? RB_OP_N : RB_OP_T, tb = opb == 'N' ? RB_OP_N : RB_OP_T;
   const int algo = solution ? RB_ALGO_SOLUTION_INDEX : RB_ALGO_STANDARD;

@@ -82,9 +82,10 @@ inline void gemm_out(Tensor& out, const Tensor& a, const Tensor& b, void* stream
       const auto it = g_gemm_table.find(key);
       if (it != g_gemm_table.end()) {
         const int64_t sa = b.dim() == 3 ? b.stride(0) : 0, sb = a.dim() == 3 ? a.stride(0) : 0, sc = batched ? out.stride(0) : 0;
-        check(mm_gemm_f32((char)(opa - 32), (char)(opb - 32), (int)n, (int)m, (int)k, 1.0f, fp(b), (int)lda, sa, fp(a), (int)ldb, sb, 0.0f,
-                          fpm(out), (int)ldc, sc, batched ? (int)out.size(0) : 1, it->second, stream), "mm_gemm_f32");
-        return;
+        const int rc = mm_gemm_f32((char)(opa - 32), (char)(opb - 32), (int)n, (int)m, (int)k, 1.0f, fp(b), (int)lda, sa, fp(a), (int)ldb,
+                                   sb, 0.0f, fpm(out), (int)ldc, sc, batched ? (int)out.size(0) : 1, it->second, stream);
+        if (rc == MM_OK) return;
+        if (rc != MM_ERR_UNSUPPORTED) check(rc, "mm_gemm_f32");       // UNSUPPORTED: a first call on a capturing stream -> ATen below
       }
     }
   }

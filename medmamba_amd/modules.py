@@ -45,8 +45,10 @@ _GRAPH_BLOCK_MAX_L = int(__import__("os").environ.get("MM_GRAPH_BLOCK_MAX_L", "0
 _SIDE_STREAMS = {}
 _CONV_WARM = set()      # conv-branch input shapes whose MIOpen solver search has run (SS_Conv_SSM.forward)
 _CONV_COLD_RUNS = {}
-# images with at least this many positions start the side stream when the scan kernel is queued (see SS_Conv_SSM.forward)
-_LATE_SIDE_MIN_L = int(__import__("os").environ.get("MM_LATE_SIDE_MIN_L", "2048"))
+# images with at least this many positions start the side stream when the scan kernel is queued (see SS_Conv_SSM.forward).
+# Default since the host stopped limiting the queues (round 3): never — the side stream starts at the split at every stage
+# (29.02 / 29.12 vs 29.29 / 29.32 ms per MedMamba-S step with the 56x56 stage started late; MedMamba-B at 384^2: no difference)
+_LATE_SIDE_MIN_L = int(__import__("os").environ.get("MM_LATE_SIDE_MIN_L", str(1 << 30)))
 
 
 def _has_hooks(module):
