@@ -584,10 +584,9 @@ class SS_Conv_SSM(nn.Module):
             side = _side_stream(input.device)
             left.record_stream(side)       # allocated on `main`, read by the side stream in forward and backward
             if left.shape[2] * left.shape[3] >= _LATE_SIDE_MIN_L:
-                # long sequences: queue the SS2D branch first and let the side stream start when the scan kernel does — the
-                # conv kernels then share the GPU with the latency-bound scan instead of with the bandwidth-bound projections
-                # before it (same step time, measured; the scan runs 15 % faster inside the step).  For short sequences
-                # the late start would only delay the join below.
+                # (off by default, see _LATE_SIDE_MIN_L) long sequences: queue the SS2D branch first and let the side stream start
+                # when the scan kernel does — the conv kernels then share the GPU with the latency-bound scan instead of with
+                # the bandwidth-bound projections before it.  For short sequences the late start only delays the join below.
                 ev = torch.cuda.Event()
                 x_cf = self.self_attention.forward_cf(right_n, prescan_event=ev)             # (B, C/2, H*W)
                 side.wait_event(ev)
