@@ -10,6 +10,9 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "lib", "libmedmamba_hip.so")
+# A/B measurements of two builds of the SAME ABI on one box (tools/): MM_HIP_LIB names another .so; never a fallback
+if os.environ.get("MM_HIP_LIB"):
+    SO_PATH = os.path.abspath(os.environ["MM_HIP_LIB"])
 
 ABI_VERSION = 20        # == MM_ABI_VERSION of include/medmamba_hip.h (checked when the library is loaded)
 _f32p = ctypes.c_void_p

@@ -29,8 +29,8 @@ namespace {
 using namespace mm;
 
 constexpr int fwd_tile(int ns, bool lean) { return (lean && ns >= 2) ? 32 : 64; }
-// B / C tiles lie in LDS as [time step][16 states] rows of kBCS floats (16 + 4 pad: 16-B aligned rows, and the staging writes of
-// a wave spread over the banks): the NS states of a lane at one time step are ONE ds_read_b32/b64/b128, and they arrive as
+// B / C tiles lie in LDS as [position][16 states] rows of kBCS floats (16 + 4 pad: 16-B aligned rows; the rows are ordered by
+// quad component first, see the staging stores): the NS states of a lane at one time step are ONE ds_read_b32/b64/b128, and they arrive as
 // adjacent registers — operand pairs of v_pk_fma_f32 / v_pk_mul_f32 (two states per instruction)
 // (18 for 2 states per lane: 8-B aligned rows suffice for ds_read_b64, and 2 x 64 x 20 floats would push a 2-wave workgroup
 // over 160 KB / 6 — the 56x56 stage runs 3072 such waves and needs all 3 per SIMD resident at once)
@@ -233,8 +233,12 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(const FwdParams p) {
       const int n = (k % (NBC / 2)) * RPI + r;
       const bool isC = k >= NBC / 2;
       const float4 v = LEAN ? load_quad<VEC, VEC>(isC ? rC : rB, bcoff[k], t0 + 4 * q, p.L, rev, true) : pbc[LEAN ? 0 : k];
-      float* dst = s_bc + ((isC ? kTile : 0) + 4 * qc) * kBCS + n;      // 4 positions of state n (transposed into [t][n])
-      dst[0] = v.x; dst[kBCS] = v.y; dst[2 * kBCS] = v.z; dst[3 * kBCS] = v.w;
+      // 4 positions of state n, transposed into [position][n] rows.  Position p = 4*column + e lies in row e*QL + column (rows
+      // grouped by quad component): consecutive lanes of one ds_write_b32 then write CONSECUTIVE rows, 20 (18) floats apart, so
+      // the 32 lanes of a bank group spread over >= 16 banks (2-way at most, which a b32 store hides) — with rows in position order
+      // the lanes were 4 rows = 80 floats = 16 banks apart and only 4 banks took all 32 stores (8-way)
+      float* dst = s_bc + ((isC ? kTile : 0) + qc) * kBCS + n;
+      dst[0] = v.x; dst[QL * kBCS] = v.y; dst[2 * QL * kBCS] = v.z; dst[3 * QL * kBCS] = v.w;
     }
     // the previous tile's stores go out here: older than the loads issued next, so the wait for those
     // loads (one recurrence later) retires them for free and every path sees the same vmcnt picture
@@ -263,7 +267,8 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(const FwdParams p) {
       o.du4 = *reinterpret_cast<const float4*>(s_du + c * kTileStride + 4 * col);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int row = RV ? kTile - 1 - (4 * tg + e) : 4 * tg + e;
+        // step e of group tg is position 4*tg + e (mirrored tile: kTile-1-(4*tg+e) = 4*(QL-1-tg) + 3-e) -> row component*QL + column
+        const int row = RV ? (3 - e) * QL + (QL - 1 - tg) : e * QL + tg;
         load_row(sB + row * kBCS, o.Bt[e]);
         load_row(sC + row * kBCS, o.Ct[e]);
       }
