@@ -13,8 +13,10 @@
  *
  * Conventions (all entry points):
  *   - plain pointers + sizes, no C++/torch types; every pointer is a DEVICE pointer owned by the caller
- *   - the library allocates nothing, keeps no state, never synchronises: kernels are enqueued on the
- *     hipStream_t passed as `stream` (NULL = default stream) and the call returns immediately
+ *   - the library allocates nothing, never synchronises, and keeps no state — with ONE exception since ABI 20: after
+ *     mm_blas_attach, mm_gemm_f32 keeps one rocBLAS handle (and that handle's device workspace) per host thread, device and
+ *     stream for the life of the thread.  Kernels are enqueued on the hipStream_t passed as `stream` (NULL = default
+ *     stream) and the call returns immediately
  *   - return 0 on success; < 0 = mm_status (bad argument / unsupported variant, nothing launched);
  *     > 0 = hipError_t of the failed launch.  Nothing throws across the ABI.
  *   - fp32 everywhere (the reference path is fp32: MedMamba.py:265-271, 280, 297)
@@ -57,9 +59,15 @@ enum mm_status {
  * size it).  Required by mm_scan_bwd; pass NULL to mm_scan_fwd for inference.
  *
  * Backward (mm_scan_bwd): dout (batch, dim, L) contiguous in; du, ddelta (batch, dim, L) contiguous
- * out (fully written); dB, dC (batch, G, N, L) contiguous; dA (dim, N), dD (dim), ddelta_bias (dim):
- * ACCUMULATED into (atomicAdd across batch / channel tiles) — the caller zero-fills dA, dB, dC, dD,
- * ddelta_bias before the call.  dD / ddelta_bias may be NULL when D / delta_bias are NULL.
+ * out (fully written); dB, dC (batch, G, N, L) contiguous; dA (dim, N), dD (dim), ddelta_bias (dim).
+ * Two output forms for the parameter / B / C gradients:
+ *   - deterministic (since ABI 19; what medmamba_amd itself uses: dpar_sb / dBC_sc below non-zero): every output element has
+ *     exactly one writer, plain stores, nothing to zero-fill, bitwise reproducible; the caller sums the per-batch-item
+ *     (dA, dD, ddelta_bias) and per-workgroup (dB, dC) partials in an order of its choice;
+ *   - accumulating (dpar_sb == dBC_sc == 0, the ABI <= 18 behaviour, kept for callers built against older headers): dA, dD,
+ *     ddelta_bias — and dB, dC where several workgroups share a direction — are ADDED into with fp32 atomics, so the caller
+ *     zero-fills them before the call and the result depends on the order in which the adds land.
+ * dD / ddelta_bias may be NULL when D / delta_bias are NULL.
  *
  * The struct is SELF-DESCRIBING (since ABI 18): `struct_size` = sizeof(mm_scan_args) of the header the caller was built against.
  * The library accepts exactly the sizes at which a release of this header ended the struct — MM_SCAN_ARGS_SIZE_BASE (through
@@ -297,6 +305,11 @@ int mm_bn_fused(int batch, int C, int HW);
 int mm_bn_relu_bwd(const float* dy, const float* x, const float* gamma, const float* beta, const float* mean, const float* rstd,
                    float* dx, float* dgamma, float* dbeta, float* ws, float* dxsum, int relu, int batch, int C, int HW, void* stream);
 
+#ifdef MM_EXPERIMENTS
+/* ---- EXPERIMENTS build only (lib/libmedmamba_hip_exp.so, `python -m medmamba_amd.build --experiments`): not part of the product
+ * library.  Own dense 3x3 convolutions (correct, slower than MIOpen, kept as a measured experiment), and the
+ * forward scan's timing-ablation bits: mm_scan_args.variant bits 8-15 (1 = no y store, 2 = no recurrence; results are WRONG when
+ * set).  The product library ignores those bits. ---- */
 /* Dense 3x3 convolution, padding 1, stride 1, of the conv branch (MedMamba.py:339, 342), forward, fp32 on the matrix cores:
  *   y[b,k,h,w] = bias[k] + sum_{c,r,s} w[k,c,r,s] * x'[b,c,h+r-1,w+s-1];  x, y contiguous NCHW, w (K, C, 3, 3), bias (K) or NULL.
  *   in_affine = [scale C | shift C] or NULL: x' = x*scale[c] + shift[c] (then ReLU if in_relu) inside the image, 0 in the padding —
@@ -314,6 +327,7 @@ int mm_conv3x3_fwd(const float* x, const float* w, const float* bias, const floa
 int mm_conv3x3_v2_tiles(int batch, int H, int W);
 int mm_conv3x3_v2_fwd(const float* x, const float* wt, const float* bias, const float* in_affine, int in_relu, float* y, float* stats,
                       int batch, int C, int K, int H, int W, void* stream);
+#endif /* MM_EXPERIMENTS */
 
 /* SS2D parameters (MedMamba.py:150-175) -> one buffer in kernel direction order, A = -exp(A_logs) (MedMamba.py:271):
  *   x_proj_w (4, C, D), dt_w (4, D, R), dt_b (4, D), A_logs (4*D, N), Ds (4*D) in the reference's direction order

@@ -88,10 +88,6 @@ SYMBOLS = {
                        + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
     "mm_bn_relu_fwd_stats": (ctypes.c_int, [_f32p, _f32p, ctypes.c_int, _f32p, _f32p, ctypes.c_float, ctypes.c_float, _f32p, _f32p, _f32p, _f32p,
                                             _f32p] + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
-    "mm_conv3x3_fwd_tiles": (ctypes.c_int, [ctypes.c_int] * 3),
-    "mm_conv3x3_fwd": (ctypes.c_int, [_f32p] * 4 + [ctypes.c_int, _f32p, _f32p] + [ctypes.c_int] * 5 + [ctypes.c_void_p]),
-    "mm_conv3x3_v2_tiles": (ctypes.c_int, [ctypes.c_int] * 3),
-    "mm_conv3x3_v2_fwd": (ctypes.c_int, [_f32p] * 4 + [ctypes.c_int, _f32p, _f32p] + [ctypes.c_int] * 5 + [ctypes.c_void_p]),
     "mm_bn_fused": (ctypes.c_int, [ctypes.c_int] * 3),
     "mm_bn_relu_bwd": (ctypes.c_int, [_f32p] * 11 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
     "mm_channel_sum_nchw_split": (ctypes.c_int, [ctypes.c_int] * 2),
@@ -116,7 +112,17 @@ SYMBOLS = {
                                    ctypes.c_void_p]),
 }
 
+# entry points that only the experiments build exports (include/medmamba_hip.h, #ifdef MM_EXPERIMENTS)
+EXP_SYMBOLS = {
+    "mm_conv3x3_fwd_tiles": (ctypes.c_int, [ctypes.c_int] * 3),
+    "mm_conv3x3_fwd": (ctypes.c_int, [_f32p] * 4 + [ctypes.c_int, _f32p, _f32p] + [ctypes.c_int] * 5 + [ctypes.c_void_p]),
+    "mm_conv3x3_v2_tiles": (ctypes.c_int, [ctypes.c_int] * 3),
+    "mm_conv3x3_v2_fwd": (ctypes.c_int, [_f32p] * 4 + [ctypes.c_int, _f32p, _f32p] + [ctypes.c_int] * 5 + [ctypes.c_void_p]),
+}
+EXP_SO_PATH = os.path.join(_HERE, "lib", "libmedmamba_hip_exp.so")
+
 _lib = None
+_exp = None
 
 
 class MedMambaHipError(RuntimeError):
@@ -142,6 +148,27 @@ def lib():
             raise MedMambaHipError("libmedmamba_hip.so ABI version mismatch; rebuild")
         _lib = handle
     return _lib
+
+
+def _bind(path, symbols):
+    handle = ctypes.CDLL(path)
+    for name, (res, args) in symbols.items():
+        fn = getattr(handle, name)      # AttributeError if the .so is stale
+        fn.restype, fn.argtypes = res, args
+    if handle.mm_abi_version() != ABI_VERSION:
+        raise MedMambaHipError(f"{os.path.basename(path)} ABI version mismatch; rebuild")
+    return handle
+
+
+def exp_lib():
+    """The EXPERIMENTS build of the library (`python -m medmamba_amd.build --experiments`): everything the product library has plus
+    the measured-and-rejected experiments.  Only tests / tools / the opt-in MM_OWN_CONV=1 route call this; None when not built."""
+    global _exp
+    if _exp is None:
+        if not os.path.exists(EXP_SO_PATH):
+            return None
+        _exp = _bind(EXP_SO_PATH, {**SYMBOLS, **EXP_SYMBOLS})
+    return _exp
 
 
 def check(rc, what):

@@ -77,6 +77,13 @@ def load_table(path):
     # solution indices belong to one rocBLAS build: TunableOp records rocblas_get_version_string(), compare with the loaded library
     if have is None or recorded.get("ROCBLAS_VERSION") != have:
         return 0
+    # ... and to one GPU architecture within that build (torch's own TunableOp validator compares GCN_ARCH_NAME the same way)
+    try:
+        arch = torch.cuda.get_device_properties(torch.cuda.current_device()).gcnArchName
+    except (AttributeError, RuntimeError):
+        arch = None
+    if recorded.get("GCN_ARCH_NAME") is not None and arch is not None and recorded["GCN_ARCH_NAME"] != arch:
+        return 0
     if not attach():
         return 0
     for r in rows:
@@ -142,9 +149,17 @@ def gemm(out, a, b, beta=0.0):
             STATS["torch"] += 1
             return False
         sol = 0
-    rc = _lib.lib().mm_gemm_f32(opa.upper().encode(), opb.upper().encode(), n, m, k, 1.0, b.data_ptr(), lda, sa, a.data_ptr(), ldb, sb,
-                                beta, out.data_ptr(), ldc, sc, batch, sol, _lib.raw_stream())
+    # handle and stream are those of the CURRENT device inside mm_gemm_f32: make the tensors' device current (like every other launch)
+    with _lib.device_guard(out.device):
+        rc = _lib.lib().mm_gemm_f32(opa.upper().encode(), opb.upper().encode(), n, m, k, 1.0, b.data_ptr(), lda, sa, a.data_ptr(), ldb,
+                                    sb, beta, out.data_ptr(), ldc, sc, batch, sol, _lib.raw_stream())
     if rc == -3:          # MM_ERR_UNSUPPORTED: first call on a stream that is being captured into a hipGraph — the caller uses torch
+        return False
+    if rc == -6 and sol != 0 and _lib.lib().mm_blas_attached():
+        # MM_ERR_BLAS for a RECORDED solution (e.g. an index this GPU / build does not know: rocblas_status_invalid_value):
+        # forget the record (the C++ layer does the same for its own copy) and let torch run this product from now on
+        _TABLE.pop(key, None)
+        STATS["torch"] += 1
         return False
     if rc != 0:
         raise _lib.MedMambaHipError(f"mm_gemm_f32 failed: status {rc}, rocBLAS status {_lib.lib().mm_blas_last_status()} for {key[1]}")

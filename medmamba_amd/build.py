@@ -1,6 +1,10 @@
 """Build libmedmamba_hip.so for gfx950 with hipcc (no torch headers, no pybind; plain C ABI).
 
-    python -m medmamba_amd.build [--force] [--verbose]
+    python -m medmamba_amd.build [--force] [--verbose] [--experiments]
+
+--experiments additionally builds lib/libmedmamba_hip_exp.so from the same sources with -DMM_EXPERIMENTS: the product library plus
+the measured-and-rejected experiments (own dense 3x3 convolutions, csrc/conv.hip; the forward scan's timing-ablation bits).  Only
+tests / tools that exercise those load it (_lib.exp_lib()); the product path never does.
 
 hipcc cross-compiles without a GPU; the .so lands in medmamba_amd/lib/ (git-ignored, travels with
 gpurun snapshots).
@@ -29,12 +33,20 @@ def _deps():
     return hdrs
 
 
-def build(force=False, verbose=False, extra=()):
+EXP_SO = os.path.join(LIBDIR, "libmedmamba_hip_exp.so")
+
+
+def build(force=False, verbose=False, extra=(), experiments=False):
+    """The product library; experiments=True: the experiments variant (own object directory, own .so) instead."""
     os.makedirs(LIBDIR, exist_ok=True)
+    objdir, so = (os.path.join(LIBDIR, "exp"), EXP_SO) if experiments else (LIBDIR, SO)
+    os.makedirs(objdir, exist_ok=True)
+    if experiments:
+        extra = tuple(extra) + ("-DMM_EXPERIMENTS",)
     objs, dep_m = [], max(os.path.getmtime(h) for h in _deps())
     procs = []
     for src in sources():
-        obj = os.path.join(LIBDIR, os.path.basename(src)[:-4] + ".o")
+        obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
         objs.append(obj)
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), dep_m):
             cmd = [HIPCC, *FLAGS, *extra, "-c", src, "-o", obj]
@@ -44,12 +56,12 @@ def build(force=False, verbose=False, extra=()):
     for src, pr in procs:
         if pr.wait() != 0:
             raise RuntimeError(f"hipcc failed on {src}")
-    if procs or not os.path.exists(SO):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO, *objs]
+    if procs or not os.path.exists(so):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so, *objs]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
-    return SO
+    return so
 
 
 # ---- the C++ sequencing layer (csrc_host/*.cpp): a torch extension without device code, compiled with g++ against torch's
@@ -84,3 +96,5 @@ def build_host(force=False, verbose=False):
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
     print(build_host(force="--force" in sys.argv, verbose=True))
+    if "--experiments" in sys.argv:
+        print(build(force="--force" in sys.argv, verbose=True, experiments=True))

@@ -13,6 +13,7 @@ typedef void* rb_handle;
 enum { RB_OP_N = 111, RB_OP_T = 112, RB_F32 = 151, RB_ALGO_STANDARD = 0, RB_ALGO_SOLUTION_INDEX = 1 };
 enum { RB_ATOMICS_NOT_ALLOWED = 0, RB_ATOMICS_ALLOWED = 1 };
 typedef int (*create_fn)(rb_handle*);
+typedef int (*destroy_fn)(rb_handle);
 typedef int (*set_stream_fn)(rb_handle, hipStream_t);
 typedef int (*set_atomics_fn)(rb_handle, int);
 typedef int (*gemm_sb_fn)(rb_handle, int, int, int, int, int, const void*, const void*, int, int, int64_t, const void*, int, int,
@@ -24,6 +25,7 @@ typedef int (*gemm_fn)(rb_handle, int, int, int, int, int, const void*, const vo
 struct Blas {
   void* dl = nullptr;
   create_fn create = nullptr;
+  destroy_fn destroy = nullptr;
   set_stream_fn set_stream = nullptr;
   set_atomics_fn set_atomics = nullptr;
   gemm_sb_fn gemm_sb = nullptr;
@@ -61,6 +63,7 @@ int mm_blas_attach(const char* path) {
   Blas b;
   b.dl = dl;
   b.create = (create_fn)dlsym(dl, "rocblas_create_handle");
+  b.destroy = (destroy_fn)dlsym(dl, "rocblas_destroy_handle");
   b.set_stream = (set_stream_fn)dlsym(dl, "rocblas_set_stream");
   b.set_atomics = (set_atomics_fn)dlsym(dl, "rocblas_set_atomics_mode");
   b.gemm_sb = (gemm_sb_fn)dlsym(dl, "rocblas_gemm_strided_batched_ex");
@@ -108,9 +111,15 @@ int mm_gemm_f32(char opa, char opb, int m, int n, int k, float alpha, const floa
   Handle& hd = t_handles[key];
   if (!hd.h) {
     t_last_status = g_blas.create(&hd.h);
-    if (t_last_status != 0) { hd.h = nullptr; return MM_ERR_BLAS; }
+    if (t_last_status != 0) { hd.h = nullptr; t_handles.erase(key); return MM_ERR_BLAS; }
     t_last_status = g_blas.set_stream(hd.h, (hipStream_t)stream);
-    if (t_last_status != 0) return MM_ERR_BLAS;
+    if (t_last_status != 0) {
+      // never keep a handle that is not bound to `stream`: later calls on this key would run on the default stream
+      if (g_blas.destroy) (void)g_blas.destroy(hd.h);
+      hd.h = nullptr;
+      t_handles.erase(key);
+      return MM_ERR_BLAS;
+    }
   }
   if (hd.epoch != g_blas.atomics_epoch) {
     if (g_blas.set_atomics) (void)g_blas.set_atomics(hd.h, g_blas.atomics);

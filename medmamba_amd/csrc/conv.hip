@@ -16,6 +16,10 @@
 //             registers while the current chunk multiplies.
 //   multiply: per kappa pair one ds_read_b32 for A (weights) and two for B (im2col), two MFMAs.
 //   epilogue: accumulators -> LDS [k][n] -> (+bias) coalesced NCHW stores and the per-channel tile statistics.
+// EXPERIMENT (correct, slower than MIOpen): compiled only into the experiments build of the library
+// (`python -m medmamba_amd.build --experiments` -> lib/libmedmamba_hip_exp.so, -DMM_EXPERIMENTS); the product library does not
+// carry these kernels or their entry points.
+#ifdef MM_EXPERIMENTS
 #include "mm_common.h"
 #include "medmamba_hip.h"
 
@@ -447,42 +451,4 @@ int mm_conv3x3_v2_fwd(const float* x, const float* wt, const float* bias, const 
 }
 
 }  // extern "C"
-
-// ---- im2col of a 3x3 / padding 1 / stride 1 convolution's input, all images in ONE launch (ATen's im2col launches once per image:
-// 1792 launches per MedMamba-S step when the deterministic weight gradient below uses it) --------------------------------------
-// cols[b][c*9 + r*3 + s][h*W + w] = x[b][c][h+r-1][w+s-1] (0 outside the image): the layout of torch.nn.functional.unfold(x, 3,
-// padding=1), so that dW = sum_b dy[b] (K x HW) . cols[b]^T (HW x 9C) is the weight gradient in (K, C, 3, 3) order.  With
-// group = gs > 1 the images of a group sit side by side: cols (batch/gs, 9C, gs*HW) — one GEMM then contracts over gs images and
-// the caller sums batch/gs partial products instead of batch.
-namespace {
-__global__ __launch_bounds__(256) void im2col3x3_kernel(const float* __restrict__ x, float* __restrict__ cols, int C, int H, int W, int gs) {
-  const int HW = H * W;
-  const int plane = blockIdx.y;                   // b*C + c
-  const int b = plane / C, c = plane - b * C;
-  const float* xp = x + (int64_t)plane * HW;
-  // image j = b % gs of group g = b / gs: column block j of the group's (9C) x (gs*HW) matrix
-  float* cp = cols + (((int64_t)(b / gs) * 9 * C + (int64_t)c * 9) * gs + (b % gs)) * HW;
-  const int64_t tap = (int64_t)gs * HW;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) {
-    const int h = i / W, w = i - h * W;
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-      for (int s2 = 0; s2 < 3; ++s2) {
-        const int hh = h + r - 1, ww = w + s2 - 1;
-        cp[(r * 3 + s2) * tap + i] = (hh >= 0 && hh < H && ww >= 0 && ww < W) ? xp[hh * W + ww] : 0.f;
-      }
-  }
-}
-}  // namespace
-
-extern "C" int mm_im2col3x3(const float* x, float* cols, int batch, int C, int H, int W, int group, void* stream) {
-  if (!x || !cols) return MM_ERR_NULL;
-  if (batch <= 0 || C <= 0 || H <= 0 || W <= 0 || (int64_t)batch * C > 0x7fffffffll) return MM_ERR_SHAPE;
-  if (group < 1 || batch % group != 0) return MM_ERR_SHAPE;
-  const int HW = H * W;
-  int gx = (HW + 255) / 256;
-  if (gx > 16) gx = 16;
-  hipLaunchKernelGGL(im2col3x3_kernel, dim3(gx, batch * C), dim3(256), 0, (hipStream_t)stream, x, cols, C, H, W, group);
-  return (int)hipGetLastError();
-}
+#endif  // MM_EXPERIMENTS

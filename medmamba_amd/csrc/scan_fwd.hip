@@ -59,8 +59,16 @@ struct FwdParams {
   const float* __restrict__ dts;   // (batch, G, R, L) rows with strides (dts_sb, dts_sg, dts_sn, 1)
   int64_t dts_sb, dts_sg, dts_sn;
   int R;
-  int dbg;   // timing-only ablation bits (bench diagnostics; results are wrong when set): 1 no y store, 2 no recurrence
+#ifdef MM_EXPERIMENTS
+  int dbg;   // experiments build only — timing ablations (results are wrong when set): 1 no y store, 2 no recurrence
+#endif
 };
+// the product library has no ablation bits: the expression folds to 0 and the code they guarded disappears
+#ifdef MM_EXPERIMENTS
+#define MM_FWD_DBG(p) ((p).dbg)
+#else
+#define MM_FWD_DBG(p) 0
+#endif
 
 __device__ __forceinline__ float f4get(const float4& v, int i) {
   return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w;
@@ -189,7 +197,7 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(const FwdParams p) {
 
   float4 yreg[NLD];
   auto store_tile = [&](int t0) {
-    const bool st_en = !(p.dbg & 1);   // folded into the range check: no branch, so vmcnt stays countable
+    const bool st_en = !(MM_FWD_DBG(p) & 1);   // folded into the range check: no branch, so vmcnt stays countable
 #pragma unroll
     for (int i = 0; i < NLD; ++i) store_quad<VEC, VEC>(ro, ooff[i], t0 + 4 * q, p.L, rev, rvalid[i] && st_en, yreg[i]);
   };
@@ -249,7 +257,7 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(const FwdParams p) {
 
     // ---- phase 2: the recurrence over this tile, 4 steps per group
     const int tlen = min(kTile, p.L - t0);
-    const int ngroups = (p.dbg & 2) ? 0 : (tlen + 3) >> 2;
+    const int ngroups = (MM_FWD_DBG(p) & 2) ? 0 : (tlen + 3) >> 2;
     const float* sB = s_bc + g * NS;                               // this lane's states inside a [t][16] row
     const float* sC = s_bc + kTile * kBCS + g * NS;
     struct Ops { float4 dl4, du4; float Bt[4][NS], Ct[4][NS]; };
@@ -424,7 +432,9 @@ int scan_fwd_launch(const mm_scan_args* a, hipStream_t stream, int32_t* plan_out
   p.batch = a->batch; p.dim = a->dim; p.L = a->L; p.G = a->G; p.H = a->dim / a->G;
   p.ntiles = (a->L + kTile - 1) / kTile;
   p.nchk = (a->L + kChunk - 1) / kChunk;
+#ifdef MM_EXPERIMENTS
   p.dbg = (a->variant >> 8) & 0xff;
+#endif
   const bool shared = a->u_groups > 0 && a->u_groups < a->G;
   p.ug = shared ? a->u_groups : a->G;
   p.u_map = shared ? a->u_map : 0x76543210u;

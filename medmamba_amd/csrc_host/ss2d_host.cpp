@@ -56,7 +56,9 @@ inline Tensor rows(const Tensor& t) { return t.stride(-1) == 1 ? t : t.contiguou
 // exactly this problem — 6 instead of 17-21 us of host time per call through ATen's dispatcher + TunableOp's string-keyed lookup +
 // library front end — ATen otherwise (hipBLASLt winners, unrecorded shapes, no table).  The key is the one medmamba_amd/blas.py
 // builds (TunableOp's own): column-major problem of out^T = b^T a^T.
-std::unordered_map<std::string, int32_t> g_gemm_table;      // filled once by blas.load_table (set_gemm_table), read-only afterwards
+std::unordered_map<std::string, int32_t> g_gemm_table;      // filled once by blas.load_table (set_gemm_table); afterwards only a value
+                                                             // may change, to kDeclined (a solution the library rejected)
+constexpr int32_t kDeclined = INT32_MIN;
 
 inline bool col_operand(const Tensor& t, char& op, int64_t& ld) {
   const int64_t s0 = t.stride(-2), s1 = t.stride(-1);
@@ -80,12 +82,15 @@ inline void gemm_out(Tensor& out, const Tensor& a, const Tensor& b, void* stream
       if (batched) { key += "_B_"; key += std::to_string(out.size(0)); }
       key += "_ld_"; key += std::to_string(lda); key += '_'; key += std::to_string(ldb); key += '_'; key += std::to_string(ldc);
       const auto it = g_gemm_table.find(key);
-      if (it != g_gemm_table.end()) {
+      if (it != g_gemm_table.end() && it->second != kDeclined) {
         const int64_t sa = b.dim() == 3 ? b.stride(0) : 0, sb = a.dim() == 3 ? a.stride(0) : 0, sc = batched ? out.stride(0) : 0;
         const int rc = mm_gemm_f32((char)(opa - 32), (char)(opb - 32), (int)n, (int)m, (int)k, 1.0f, fp(b), (int)lda, sa, fp(a), (int)ldb,
                                    sb, 0.0f, fpm(out), (int)ldc, sc, batched ? (int)out.size(0) : 1, it->second, stream);
         if (rc == MM_OK) return;
-        if (rc != MM_ERR_UNSUPPORTED) check(rc, "mm_gemm_f32");       // UNSUPPORTED: a first call on a capturing stream -> ATen below
+        // BLAS: the library rejected the recorded solution (an index of another architecture / build): forget the record, ATen from
+        // here on (the value is overwritten, never erased: the autograd thread may be looking at the table too)
+        if (rc == MM_ERR_BLAS) it->second = kDeclined;
+        else if (rc != MM_ERR_UNSUPPORTED) check(rc, "mm_gemm_f32");  // UNSUPPORTED: a first call on a capturing stream -> ATen below
       }
     }
   }

@@ -28,6 +28,13 @@ def _gemm(a, b, out=None, batch=None):
     return out
 
 
+def _wants_grad(*ts):
+    """Does anything downstream differentiate this call?  Inside Function.forward grad mode is always off and
+    ctx.needs_input_grad ignores torch.no_grad(), so the wrappers decide here and pass a plain flag: under no_grad (the usual
+    eval loop with trainable parameters) the inference form — no state checkpoints, dt projection inside the scan — engages."""
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in ts)
+
+
 def _need_hip(*ts):
     for t in ts:
         if not t.is_cuda:
@@ -338,7 +345,8 @@ class SS2DCoreFn(torch.autograd.Function):
                 P[o3:o3 + 4 * D], P[o4:o4 + 4 * D])
 
     @staticmethod
-    def forward(ctx, u2, conv_w, conv_b, x_proj_w, dt_w, dt_b, A_logs, Ds, z_cf, ln_w, ln_b, H, W, eps, prescan_event=None):
+    def forward(ctx, u2, conv_w, conv_b, x_proj_w, dt_w, dt_b, A_logs, Ds, z_cf, ln_w, ln_b, H, W, eps, prescan_event=None,
+                need_grad=True):
         from .selective_scan_interface import _CROSS_SHARED, _launch_fwd, dt_fusable
         lib = _lib.lib()
         dev = u2.device
@@ -367,7 +375,7 @@ class SS2DCoreFn(torch.autograd.Function):
             rc = lib.mm_ss2d_pack_fwd(*[t.data_ptr() for t in srcs], P.data_ptr(), D, C, R, N, _stream())
         _lib.check(rc, "mm_ss2d_pack_fwd")
         Wx, Wdt, A, Dp, dbias = SS2DCoreFn._segments(P, D, C, R, N)
-        need_grad = any(ctx.needs_input_grad)
+        need_grad = bool(need_grad) and any(ctx.needs_input_grad)
         if cm:
             u2m = _cm2d(_rows(u2))                                                             # (2D, Q)
             u2 = u2m.view(2 * D, Bsz, L).permute(1, 0, 2)
@@ -515,7 +523,7 @@ class SS2DCoreFn(torch.autograd.Function):
                 dw_out = torch.cat([sc[:, :9].reshape(-1), sc[:, 9]])
         if fused_conv:
             dcw, dcb = dw_out[:9 * D].view(D, 1, 3, 3), (None if conv_b is None else dw_out[9 * D:])
-        return (du2, dcw, dcb, gWx, gWdt, gb.view(4, D), gA, gD, dz, ln_out[:D], ln_out[D:], None, None, None, None)
+        return (du2, dcw, dcb, gWx, gWdt, gb.view(4, D), gA, gD, dz, ln_out[:D], ln_out[D:], None, None, None, None, None)
 
 
 class SS2DBranchFn(torch.autograd.Function):
@@ -525,13 +533,14 @@ class SS2DBranchFn(torch.autograd.Function):
     interpreter between the launches (0.2 + 0.4 ms of host time per block and step)."""
 
     @staticmethod
-    def forward(ctx, x, in_w, conv_w, conv_b, x_proj_w, dt_w, dt_b, A_logs, Ds, ln_w, ln_b, out_w, H, W, eps, prescan_event):
+    def forward(ctx, x, in_w, conv_w, conv_b, x_proj_w, dt_w, dt_b, A_logs, Ds, ln_w, ln_b, out_w, H, W, eps, prescan_event,
+                need_grad=True):
         from . import _host
         from .selective_scan_interface import KERNEL_TIMER, _FWD_VARIANT, scan_bytes_fwd
         Bsz, L, _ = x.shape
         D, N = in_w.shape[0] // 2, A_logs.shape[1]
         cm = channel_major(Bsz, L)
-        need_grad = any(ctx.needs_input_grad)
+        need_grad = bool(need_grad) and any(ctx.needs_input_grad)
         x = x.contiguous()
         with _lib.device_guard(x.device):
             ev0, ev1 = KERNEL_TIMER.pair("scan_fwd", scan_bytes_fwd(Bsz, 4 * D, L, N, 4), Bsz * 4 * D * L * N)
@@ -555,7 +564,7 @@ class SS2DBranchFn(torch.autograd.Function):
             g = _host.module().ss2d_bwd(dout, x, in_w, conv_w, conv_b, ln_w, ln_b, out_w, xz, u2, x_dbl, delta, P, x_chk, m, mu, rstd, y,
                                         H, W, cm, _PACK_FOLD, _BWD_VARIANT, _stream(), ev0, ev1)
         dx, d_in, dcw, dcb, gWx, gWdt, gb, gA, gD, dlw, dlb, d_out = g
-        return dx, d_in, dcw, dcb, gWx, gWdt, gb, gA, gD, dlw, dlb, d_out, None, None, None, None
+        return dx, d_in, dcw, dcb, gWx, gWdt, gb, gA, gD, dlw, dlb, d_out, None, None, None, None, None
 
 
 def ss2d_branch_native_ok(x, mod_in_proj, mod_out_proj, conv, params):
@@ -578,7 +587,7 @@ def ss2d_branch(x_rows, in_w, conv_w, conv_b, x_proj_w, dt_w, dt_b, A_logs, Ds, 
             or tuple(conv_w.shape) != (D, 1, 3, 3) or out_w.shape[1] != D):
         raise NotImplementedError("ss2d_branch: expects 4 directions, d_state 16, a depthwise 3x3 conv over d_inner channels")
     return SS2DBranchFn.apply(x_rows, in_w, conv_w, conv_b, x_proj_w, dt_w, dt_b, A_logs, Ds, ln_w, ln_b, out_w, H, W, eps,
-                              prescan_event)
+                              prescan_event, _wants_grad(x_rows, in_w, conv_w, conv_b, x_proj_w, dt_w, dt_b, A_logs, Ds, ln_w, ln_b, out_w))
 
 
 def ss2d_core(u2, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds, z_cf, ln_w, ln_b, H, W, eps=1e-5,
@@ -593,7 +602,7 @@ def ss2d_core(u2, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds, z_c
             or x_proj_weight.shape[1] != dt_projs_weight.shape[2] + 32):
         raise NotImplementedError("ss2d_core: expects 4 directions, d_state 16, u2 with 2*D channels")
     return SS2DCoreFn.apply(u2, None, None, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds, z_cf, ln_w, ln_b, H, W,
-                            eps, prescan_event)
+                            eps, prescan_event, _wants_grad(u2, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds, z_cf, ln_w, ln_b))
 
 
 def ss2d_conv_core(x_cf, conv_weight, conv_bias, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds, z_cf, ln_w, ln_b,
@@ -608,7 +617,8 @@ def ss2d_conv_core(x_cf, conv_weight, conv_bias, x_proj_weight, dt_projs_weight,
             or x_proj_weight.shape[1] != dt_projs_weight.shape[2] + 32 or tuple(conv_weight.shape) != (D, 1, 3, 3)):
         raise NotImplementedError("ss2d_conv_core: expects 4 directions, d_state 16, a (D,1,3,3) depthwise kernel")
     return SS2DCoreFn.apply(x_cf, conv_weight, conv_bias, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds, z_cf,
-                            ln_w, ln_b, H, W, eps, prescan_event)
+                            ln_w, ln_b, H, W, eps, prescan_event,
+                            _wants_grad(x_cf, conv_weight, conv_bias, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds, z_cf, ln_w, ln_b))
 
 
 def channel_sum_nchw(x):
@@ -879,7 +889,8 @@ def nchw_ln_rows(x, gamma, beta, eps):
     return NchwLNRowsFn.apply(x, gamma, beta, eps)
 
 
-_OWN_CONV = os.environ.get("MM_OWN_CONV", "0") == "1"     # dense 3x3 convs of the conv branch (forward) through csrc/conv.hip
+_OWN_CONV = os.environ.get("MM_OWN_CONV", "0") == "1"     # experiment: dense 3x3 convs (forward) through csrc/conv.hip — needs the
+                                                          # experiments build (python -m medmamba_amd.build --experiments)
 
 
 class Conv3x3Fn(torch.autograd.Function):
@@ -894,7 +905,7 @@ class Conv3x3Fn(torch.autograd.Function):
         b = None if b is None else b.float().contiguous()
         B, C, H, W = x.shape
         K = w.shape[0]
-        lib = _lib.lib()
+        lib = _lib.exp_lib()          # an experiment: lives in the experiments build of the library only
         y = torch.empty((B, K, H, W), device=x.device, dtype=torch.float32)
         stats = torch.empty((lib.mm_conv3x3_fwd_tiles(B, H, W), K, 3), device=x.device, dtype=torch.float32) if want_stats else None
         with _lib.device_guard(x.device):
@@ -919,7 +930,7 @@ class Conv3x3Fn(torch.autograd.Function):
 
 
 def own_conv3x3_ok(x, conv):
-    return (_OWN_CONV and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and conv.kernel_size == (3, 3)
+    return (_OWN_CONV and _lib.exp_lib() is not None and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and conv.kernel_size == (3, 3)
             and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1
             and conv.padding_mode == "zeros")
 

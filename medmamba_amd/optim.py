@@ -81,7 +81,7 @@ class FusedAdamW(torch.optim.AdamW):
         i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=dev)
         return dict(P=i64([p.data_ptr() for p in params]), M=i64([t.data_ptr() for t in exp_avgs]), V=i64([t.data_ptr() for t in exp_avg_sqs]),
                     N=i64(numel), ct=i32(ct), ci=i32(ci), groups=groups, ptrs=tuple(p.data_ptr() for p in params), numel=numel,
-                    step=float(host_steps[0]), dev=dev, lib=lib, _lib=_lib)
+                    step=float(host_steps[0]), dev=dev, lib=lib, _lib=_lib, written=tuple(ts))
 
     def _hip_step(self, plan, grads):
         """One mm_adamw_step launch per <= 448 tensors.  False (nothing done) if a tensor moved or a gradient is not dense fp32."""
@@ -105,6 +105,9 @@ class FusedAdamW(torch.optim.AdamW):
                                        h["ct"].data_ptr() + 4 * c0, h["ci"].data_ptr() + 4 * c0, nc, group["lr"], beta1, beta2,
                                        group["eps"], group["weight_decay"], h["step"], stream)
                 _lib.check(rc, "mm_adamw_step")
+        # the kernel wrote parameters and moments through raw pointers: bump their version counters as torch's _fused_adamw_ does —
+        # SS_Conv_SSM._eval_fold and GraphedInference key their caches on (data_ptr, _version) and must see an optimizer step
+        torch.autograd.graph.increment_version(h["written"])
         return True
 
     @torch.no_grad()

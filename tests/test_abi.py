@@ -12,10 +12,15 @@ import medmamba_amd
 from medmamba_amd import _lib
 
 
-def _declared_symbols():
+def _declared_symbols(experiments=False):
+    """Entry points the header declares; the `#ifdef MM_EXPERIMENTS` section belongs to the experiments build only."""
     hdr = open(os.path.join(ROOT, "include", "medmamba_hip.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    return sorted(set(re.findall(r"\b(mm_[a-z0-9_]+)\s*\(", hdr)))
+    exp = "".join(re.findall(r"#ifdef MM_EXPERIMENTS(.*?)#endif", hdr, flags=re.S))
+    if not experiments:
+        hdr = re.sub(r"#ifdef MM_EXPERIMENTS.*?#endif", "", hdr, flags=re.S)
+    syms = sorted(set(re.findall(r"\b(mm_[a-z0-9_]+)\s*\(", hdr)))
+    return (syms, sorted(set(re.findall(r"\b(mm_[a-z0-9_]+)\s*\(", exp)))) if experiments else syms
 
 
 def test_library_exports_every_declared_symbol():
@@ -28,6 +33,14 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(h, name), name
         assert name in _lib.SYMBOLS, f"{name} declared in the header but not bound in _lib.SYMBOLS"
     assert set(_lib.SYMBOLS) <= set(decl)
+    # the experiments (own dense convolutions, ablation bits) are NOT in the product library; the experiments build has both sets
+    all_syms, exp_only = _declared_symbols(experiments=True)
+    assert exp_only and set(exp_only) == set(_lib.EXP_SYMBOLS)
+    for name in exp_only:
+        assert not hasattr(h, name), f"{name} is an experiment and must not ship in libmedmamba_hip.so"
+    he = ctypes.CDLL(build(experiments=True))
+    for name in all_syms:
+        assert hasattr(he, name), name
     assert _lib.lib().mm_abi_version() == _lib.ABI_VERSION == int(re.search(r"#define MM_ABI_VERSION (\d+)", open(os.path.join(ROOT, "include", "medmamba_hip.h")).read()).group(1))
     assert _lib.scan_chunk() == 16
     assert b"unsupported" in _lib.lib().mm_status_string(-3)

@@ -551,7 +551,8 @@ def test_own_conv3x3_forward_vs_fp64(shape, mode, version):
     w = torch.randn(K, C, 3, 3, device=DEV, generator=g) / (3.0 * C ** 0.5)
     b = None if mode == "nobias" else torch.randn(K, device=DEV, generator=g)
     aff = torch.cat([torch.rand(C, device=DEV, generator=g) + 0.5, torch.randn(C, device=DEV, generator=g) * 0.3]) if mode == "affine_relu" else None
-    lib = _lib.lib()
+    lib = _lib.exp_lib()          # the experiments build (lib/libmedmamba_hip_exp.so); the product library has no conv kernels
+    assert lib is not None, "python -m medmamba_amd.build --experiments"
     y = torch.empty(B, K, H, W, device=DEV)
     if version == 1:
         stats = torch.empty(lib.mm_conv3x3_fwd_tiles(B, H, W), K, 3, device=DEV)
@@ -619,9 +620,10 @@ def test_own_conv_branch_matches_miopen_branch(monkeypatch):
         assert float((res[True][3][k] - v).abs().max()) <= 1e-5 * max(1.0, float(v.abs().max())), k
 
 
-@pytest.mark.parametrize("shape", [(3, 5, 7, 9), (2, 48, 56, 56), (4, 16, 1, 1), (1, 3, 2, 300)])
+@pytest.mark.parametrize("shape", [(3, 5, 7, 9), (2, 48, 56, 56), (4, 16, 1, 1), (1, 3, 2, 300), (180, 384, 2, 2)])
 def test_im2col3x3_is_unfold(shape):
-    """mm_im2col3x3 (every image in one launch) == torch.nn.functional.unfold(x, 3, padding=1) bit for bit."""
+    """mm_im2col3x3 (every image in one launch) == torch.nn.functional.unfold(x, 3, padding=1) bit for bit.  The last shape has
+    batch * C = 69120 planes, beyond HIP's 65535 limit of grid.y (384 channels from 171 images on)."""
     from medmamba_amd import _lib
     B, C, H, W = shape
     x = torch.randn(*shape, device=DEV)

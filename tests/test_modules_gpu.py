@@ -705,3 +705,31 @@ def test_deterministic_mode_weight_gradient_of_the_dense_convs(monkeypatch):
         assert torch.equal(g1[k], g3[k]), k           # C++ route vs Python route
         scale = max(1e-4, float(g0[k].abs().max()))
         assert float((g1[k] - g0[k]).abs().max()) <= 2e-4 * scale, k
+
+
+@pytest.mark.parametrize("native", [True, False])
+def test_no_grad_forward_with_trainable_parameters_takes_the_inference_form(native, monkeypatch):
+    """ctx.needs_input_grad ignores torch.no_grad(), so eval() + no_grad() with requires_grad parameters (bench config 2,
+    trainer.evaluate, GraphedInference) used to write state checkpoints and run the dt GEMM.  The wrappers now pass grad mode."""
+    from medmamba_amd import modules, ops, selective_scan_interface as ssi
+    torch.manual_seed(4)
+    ss = modules.SS2D(d_model=24, d_state=16, expand=2).to(DEV).eval()
+    assert all(p.requires_grad for p in ss.parameters())
+    x = torch.randn(2, 8, 8, 24, device=DEV)
+    seen = []
+    real_apply = ops.SS2DBranchFn.apply
+    monkeypatch.setattr(ops.SS2DBranchFn, "apply", lambda *a: (seen.append(("branch", a[-1])), real_apply(*a))[1])
+    real_launch = ssi._launch_fwd
+    monkeypatch.setattr(ssi, "_launch_fwd", lambda *a, **k: (seen.append(("launch", a[8], k.get("dt") is not None)), real_launch(*a, **k))[1])
+    if not native:
+        monkeypatch.setattr(ops, "ss2d_branch_native_ok", lambda *a: False)
+    with torch.no_grad():
+        y0 = ss.forward_cf(x)
+    if native:
+        assert seen == [("branch", False)]
+    else:
+        assert seen == [("launch", False, True)], seen      # no checkpoints, dt projection fused (rank 2 <= mm_scan_dt_max)
+    seen.clear()
+    y1 = ss.forward_cf(x)                                   # grad mode on: the training form
+    assert seen == ([("branch", True)] if native else [("launch", True, False)]), seen
+    assert y1.requires_grad and torch.allclose(y0, y1, rtol=1e-5, atol=1e-6)

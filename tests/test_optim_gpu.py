@@ -85,3 +85,41 @@ def test_full_model_update_in_one_launch():
     assert h is not None and len(h["groups"]) == 1 and h["groups"][0][1] == len(list(net.parameters()))
     worst = max(float((a - b).abs().max()) for a, b in zip(net.parameters(), ref.parameters()))
     assert worst <= 1e-6, worst
+
+
+def test_hip_adamw_step_is_seen_by_the_version_keyed_inference_caches():
+    """mm_adamw_step writes parameters through raw pointers; the folded BatchNorm constants of
+    SS_Conv_SSM._eval_fold and GraphedInference's capture are keyed on (data_ptr, _version) and must notice the step while the
+    net stays in eval mode (frozen-BN fine-tuning; a graph kept across steps)."""
+    from medmamba_amd import optim
+    from medmamba_amd.graphs import GraphedInference
+    from medmamba_amd.modules import SS_Conv_SSM, VSSM
+    torch.manual_seed(3)
+    net = VSSM(num_classes=3, depths=[1, 1, 1, 1], dims=[16, 32, 64, 128], drop_path_rate=0.0).to(DEV).eval()
+    x = torch.randn(2, 3, 64, 64, device=DEV)
+    params = list(net.parameters())
+    v0 = [p._version for p in params]
+    opt = optim.FusedAdamW(params, lr=5e-2, weight_decay=0.0)
+    g = torch.Generator(device=DEV).manual_seed(9)
+    graphed = GraphedInference(net, x)
+    for step in range(3):                    # step 0 is torch's own (creates the state); from step 1 on the HIP launch
+        with torch.no_grad():
+            before = net(x).clone()          # builds / reuses the fold
+        for p in params:
+            p.grad = torch.randn(p.shape, device=DEV, generator=g)
+        opt.step()
+        with torch.no_grad():
+            after = net(x).clone()
+            for m in net.modules():
+                if isinstance(m, SS_Conv_SSM):
+                    m._fold_cache = None
+            fresh = net(x)
+        assert not torch.equal(before, after)
+        assert torch.equal(after, fresh), f"stale folded constants after optimizer step {step}"
+    assert opt._plans and opt._plans[0][5] is not None, "the HIP update did not engage"
+    assert all(p._version >= v + 3 for p, v in zip(params, v0))
+    n = graphed.captures
+    out = graphed(x)
+    assert graphed.captures == n + 1, "GraphedInference replayed a graph captured before the optimizer steps"
+    with torch.no_grad():
+        assert torch.allclose(out, net(x), rtol=1e-5, atol=1e-6)

@@ -29,7 +29,7 @@ def timeit(fn, iters=30, warmup=10):
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
     dev = torch.device("cuda:0")
-    lib = _lib.lib()
+    lib = _lib.exp_lib()      # python -m medmamba_amd.build --experiments
     st = torch.cuda.current_stream().cuda_stream
     print(f"{'shape':<22} {'miopen conv+bias us':>20} {'bn (stats+apply) us':>20} {'bn apply only us':>17} {'own conv+bias+stats us':>23} {'TFLOP/s own':>12}")
     for C, HW in [(48, 56), (96, 28), (192, 14), (384, 7)]:
