@@ -140,6 +140,32 @@ def cpu_baseline_subprocess(size, res, timeout_s=240, fn="cpu_baseline", mode="t
         return dict(value=None, unit="images/s", cores=0, kind="port", sample=f"cpu leg exceeded {timeout_s} s")
 
 
+def step_census(step):
+    """One profiled step (torch.profiler, device activities only): kernel launches per step and which MIOpen solver family ran the
+    dense convolutions on THIS box (MIOpen picks by on-the-spot timing; Winograd and implicit GEMM are a near tie at 14x14)."""
+    import collections
+    import re
+    from torch.autograd import DeviceType
+    from torch.profiler import ProfilerActivity, profile
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        step()
+        torch.cuda.synchronize()
+    fam = collections.Counter()
+    launches = 0
+    families = [(r"miopenSp3AsmConv|[Ww]inograd", "winograd"), (r"igemm_fwd", "igemm_fwd"), (r"igemm_bwd", "igemm_bwd"),
+                (r"igemm_wrw", "igemm_wrw"), (r"naive_conv|Conv.*[Dd]irect|gcnAsmConv", "direct"), (r"batched_transpose", "layout_transpose"),
+                (r"Im2[dD]?[cC]ol|im2col", "im2col")]
+    for e in prof.key_averages():
+        if e.device_type != DeviceType.CUDA or re.search(r"[Mm]emcpy|[Mm]emset", e.key):
+            continue
+        launches += e.count
+        for pat, name in families:
+            if re.search(pat, e.key):
+                fam[name] += e.count
+                break
+    return {"launches_per_step": launches, "conv_kernel_families": dict(fam)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -190,10 +216,11 @@ def main():
     if world > 1:
         from medmamba_amd.trainer import offset_device_rng
         offset_device_rng(rank, 42)             # identical weights above; DropPath masks drawn per rank from here on
-    # gradient exchange: one flat all-reduce after backward (GradSync) unless MM_DDP=torch asks for DistributedDataParallel
-    use_torch_ddp = world > 1 and os.environ.get("MM_DDP", "flat") == "torch"
+    # gradient exchange: GradSync (bucketed, overlapped with backward) unless MM_DDP=torch asks for DistributedDataParallel
+    use_torch_ddp = world > 1 and os.environ.get("MM_DDP", "bucketed") == "torch"
     model = wrap_ddp(net, dev) if use_torch_ddp else net
-    sync = GradSync(net) if (world > 1 and not use_torch_ddp) else None
+    # MM_DDP=flat: GradSync(overlap=False), one all-reduce after backward; default: per-stage buckets started during backward
+    sync = GradSync(net, overlap=os.environ.get("MM_DDP", "bucketed") != "flat", timing=True) if (world > 1 and not use_torch_ddp) else None
     # train.py:189-192 (ImageFolder branch); fused=True: same update rule, one multi-tensor kernel per step
     # MM_FUSED_ADAMW=1 (default): optim.FusedAdamW = torch.optim.AdamW(fused=True) with its per-step tensor lists cached;
     # =torch: torch.optim.AdamW(fused=True) itself; =0: torch's default (foreach) implementation
@@ -262,11 +289,52 @@ def main():
         KERNEL_TIMER.enabled = False
         _modules._TWO_STREAMS = two
         ks_iso = KERNEL_TIMER.summary()
+    dist_info = None
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        # every rank's own wall time of the timed region and the window its gradient all-reduces were in flight (device events of
+        # GradSync; with overlap this includes the backward work that ran meanwhile): a first multi-GPU run then says WHERE it loses
+        ar_ms = sync.allreduce_ms() / args.steps if sync is not None else -1.0
+        mine = torch.tensor([dt, ar_ms], device=dev, dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        dist_info = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                     "exchange": "DistributedDataParallel" if use_torch_ddp else ("GradSync bucketed" if len(sync.buckets) > 1 else "GradSync flat"),
+                     "per_rank_ms_per_step": [round(1e3 * float(t[0]) / args.steps, 3) for t in allr],
+                     "allreduce_window_ms_per_step": [round(float(t[1]), 3) for t in allr]}
+        if sync is not None:
+            dist_info.update(buckets=sync.stats["buckets"], buckets_started_in_backward=sync.stats["early"],
+                             gradient_MB=round(sum(p.numel() for p in sync.params) * 4 / 1e6, 1))
+        dt = max(float(t[0]) for t in allr)
     assert torch.isfinite(loss).item(), "loss is not finite"
+
+    # ---- untimed extras of the single-GPU training line: what one step launches, which MIOpen solver family
+    # this box picked per convolution kernel, and the step in the reference's own mode (cudnn.deterministic, train.py:28-29)
+    extras = {}
+    if rank == 0 and world == 1 and args.mode == "train" and not args.no_alone_pass:
+        try:
+            extras.update(step_census(step))
+        except Exception as e:  # noqa: BLE001 — diagnostics must never cost the bench line
+            extras["launches_per_step"] = None
+            extras["census_error"] = repr(e)[:200]
+        try:
+            prev = torch.backends.cudnn.deterministic
+            torch.backends.cudnn.deterministic = True
+            for _ in range(2):
+                step()
+            nd = max(3, args.steps // 2)
+            fence()
+            t0d = time.perf_counter()
+            for _ in range(nd):
+                step()
+            fence()
+            dtd = time.perf_counter() - t0d
+            torch.backends.cudnn.deterministic = prev
+            extras["deterministic"] = {"ms_per_step": round(1e3 * dtd / nd, 3), "value": round(args.batch * nd / dtd, 2), "steps": nd,
+                                       "note": "torch.backends.cudnn.deterministic=True, the mode the reference trains in (train.py:28-29): "
+                                               "the dense convs' weight gradient is an im2col + batched GEMM + ordered sum; every kernel "
+                                               "of this library is deterministic in both modes"}
+        except Exception as e:  # noqa: BLE001
+            extras["deterministic"] = {"ms_per_step": None, "error": repr(e)[:200]}
 
     if rank == 0:
         try:      # PMC-derived HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/scan_traffic.json)
@@ -306,11 +374,16 @@ def main():
             "config": {"workload": f"MedMamba-{args.size} {args.res}x{args.res}x3 {work}, "
                                    f"{args.batch} images per GPU resident in HBM, random-init weights",
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world,
-                       "parallelism": (f"dp{world} (replicas, " + ("DistributedDataParallel" if use_torch_ddp else
-                                       "one flat gradient all-reduce per step") + " over RCCL)") if world > 1 else "single GPU"},
+                       "parallelism": (f"dp{world} (replicas, " + (dist_info["exchange"] + " gradient all-reduce") + " over "
+                                       + ("RCCL" if dist_info["backend"] == "nccl" else dist_info["backend"]) + ")") if world > 1 else "single GPU"},
             "roofline": roof("scan_fwd"), "roofline_bwd": roof("scan_bwd"),
             "final_loss": round(float(loss.detach()), 5),
         }
+        if dist_info is not None:
+            out["distributed"] = dist_info
+        out.update(extras)
+        if out["roofline"] is not None and out["roofline"].get("traffic") is not None:
+            out["roofline"]["traffic_source"] = "profiles/scan_traffic.json @ " + str(traffic.get("measured_at_commit", "unrecorded"))
         if out["roofline_bwd"] is None:
             del out["roofline_bwd"]
         if world == 1 and not args.no_cpu_baseline:

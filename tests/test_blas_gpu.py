@@ -140,3 +140,84 @@ def test_recorded_solutions_are_used_at_full_size(monkeypatch):
     finally:
         torch.cuda.tunable.enable(False)
         blas.clear()
+
+
+def _operands_of(key, batched, g):
+    """Dense device operands for a TunableOp key `tn_m_n_k[_B_b]_ld_lda_ldb_ldc` (rocBLAS column-major terms)."""
+    p = key.split("_")
+    opa, opb = p[0][0].upper(), p[0][1].upper()
+    m, n, k = int(p[1]), int(p[2]), int(p[3])
+    batch = int(p[5]) if batched else 1
+    lda, ldb, ldc = (int(v) for v in p[-3:])
+    na = lda * (k if opa == "N" else m)
+    nb = ldb * (n if opb == "N" else k)
+    A = torch.randn(batch * na, device=DEV, generator=g)
+    B = torch.randn(batch * nb, device=DEV, generator=g)
+    return dict(opa=opa, opb=opb, m=m, n=n, k=k, batch=batch, lda=lda, ldb=ldb, ldc=ldc, sa=na, sb=nb, sc=ldc * n, A=A, B=B)
+
+
+def _ref_product(o):
+    """A(op) @ B(op) per batch item with torch (row-major views of the column-major operands), as (batch, n, m) = C^T."""
+    b = o["batch"]
+    At = o["A"].view(b, -1, o["lda"])           # column-major (lda x cols): row-major view is (cols, lda)
+    Bt = o["B"].view(b, -1, o["ldb"])
+    Aop = At[:, :o["k"], :o["m"]].transpose(1, 2) if o["opa"] == "N" else At[:, :o["m"], :o["k"]]       # (b, m, k)
+    Bop = Bt[:, :o["n"], :o["k"]].transpose(1, 2) if o["opb"] == "N" else Bt[:, :o["k"], :o["n"]]       # (b, k, n)
+    return torch.bmm(Aop, Bop).transpose(1, 2)                                                           # (b, n, m)
+
+
+def test_recorded_split_k_solutions_on_two_streams_at_once():
+    """a block's two branches issue GEMMs on two streams from one thread.  A rocBLAS handle owns ONE device
+    workspace, so mm_gemm_f32 keeps a handle per (thread, device, stream).  Here the recorded solutions of the large-K
+    weight-gradient shapes (K = B*L >= 12544: the ones rocBLAS runs split-K) are issued on two streams from this thread at the same
+    time, with different operands, and must give what the same calls give one after the other."""
+    from medmamba_amd import _lib, blas
+    from medmamba_amd.tuning import DEFAULT_FILE
+    if blas.load_table(DEFAULT_FILE) == 0:
+        pytest.skip("GEMM table not recorded for this rocBLAS build / GPU")
+    lib = _lib.lib()
+    try:
+        keys = sorted(((int(k.split("_")[3]), b, k, s) for (b, k), s in blas._TABLE.items()), reverse=True)
+        picked = [x for x in keys if x[0] >= 12544][:6] + [x for x in keys if x[1] and x[0] >= 3136][:3]
+        assert len(picked) >= 3, picked
+        g = torch.Generator(device=DEV).manual_seed(0)
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        for K, batched, key, sol in picked:
+            ops_ = [_operands_of(key, batched, g) for _ in range(2)]
+
+            def launch(o, C, stream):
+                rc = lib.mm_gemm_f32(o["opa"].encode(), o["opb"].encode(), o["m"], o["n"], o["k"], 1.0, o["A"].data_ptr(), o["lda"], o["sa"],
+                                     o["B"].data_ptr(), o["ldb"], o["sb"], 0.0, C.data_ptr(), o["ldc"], o["sc"], o["batch"], sol,
+                                     stream.cuda_stream)
+                assert rc == 0, (key, rc, lib.mm_blas_last_status())
+
+            new_c = lambda o: torch.full((o["batch"] * o["sc"],), float("nan"), device=DEV)
+            serial = []
+            for rep in range(2):                                   # one after the other (also: is this solution reproducible at all?)
+                cs = [new_c(o) for o in ops_]
+                for o, C in zip(ops_, cs):
+                    launch(o, C, torch.cuda.current_stream())
+                    torch.cuda.synchronize()
+                serial.append(cs)
+            same = lambda a, b: torch.equal(torch.nan_to_num(a, nan=7.0), torch.nan_to_num(b, nan=7.0))    # ldc > m leaves NaN pads
+            reproducible = all(same(a, b) for a, b in zip(*serial))
+            for o, C in zip(ops_, serial[0]):                      # and right
+                got = C.view(o["batch"], o["n"], o["ldc"])[:, :, :o["m"]]
+                ref = _ref_product(o)
+                assert float((got - ref).abs().max()) <= 1e-4 * max(1.0, float(ref.abs().max())), key
+            s1.wait_stream(torch.cuda.current_stream()); s2.wait_stream(torch.cuda.current_stream())
+            rounds = [[new_c(o) for o in ops_] for _ in range(6)]
+            for cs in rounds:                                      # 12 launches in flight, alternating streams, no sync in between
+                launch(ops_[0], cs[0], s1)
+                launch(ops_[1], cs[1], s2)
+            torch.cuda.synchronize()
+            for cs in rounds:
+                for C, want in zip(cs, serial[0]):
+                    if reproducible:
+                        assert same(C, want), f"{key}: concurrent result differs from the serial one"
+                    else:                                          # a solution that accumulates with atomics: equal up to summation order
+                        scale = float(want[torch.isfinite(want)].abs().max())
+                        ok = torch.isfinite(want)
+                        assert torch.equal(torch.isfinite(C), ok) and float((C[ok] - want[ok]).abs().max()) <= 1e-5 * scale, key
+    finally:
+        blas.clear()

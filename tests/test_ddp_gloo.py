@@ -47,23 +47,29 @@ def _worker(rank, world, port, outdir, mode):
             for b in net.buffers():
                 if b.is_floating_point():
                     b.add_(0.5)
-    model, sync = (wrap_ddp(net), None) if mode == "torch" else (net, GradSync(net))
+    model, sync = (wrap_ddp(net), None) if mode == "torch" else (net, GradSync(net, overlap=(mode == "bucketed")))
     g = torch.Generator().manual_seed(100)
     x = torch.randn(4, 3, 16, 16, generator=g)[2 * rank:2 * rank + 2]
     y = torch.tensor([0, 1, 2, 1])[2 * rank:2 * rank + 2]
-    loss = torch.nn.functional.cross_entropy(model(x), y)
-    loss.backward()
-    if sync is not None:
-        sync()
+    stats = []
+    for _ in range(2):                 # twice: the boundary hooks are per forward pass
+        net.zero_grad(set_to_none=True)
+        loss = torch.nn.functional.cross_entropy(model(x), y)
+        loss.backward()
+        if sync is not None:
+            sync()
+            stats.append(dict(sync.stats))
     grads = {k: p.grad.clone() for k, p in net.named_parameters()}
-    torch.save(dict(grads=grads, loss=float(loss)), os.path.join(outdir, f"r{rank}.pt"))
+    torch.save(dict(grads=grads, loss=float(loss), stats=stats, nbuckets=0 if sync is None else len(sync.buckets)),
+               os.path.join(outdir, f"r{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["flat", "torch"])
+@pytest.mark.parametrize("mode", ["bucketed", "flat", "torch"])
 def test_ddp_gradients_match_single_process(tmp_path, monkeypatch, mode):
-    """mode "flat": medmamba_amd.ddp.GradSync (one all-reduce after backward, what bench.py uses);
+    """mode "bucketed": medmamba_amd.ddp.GradSync as bench.py / train.py use it (one bucket per stage, its all-reduce started by the
+    stage-boundary hook during backward); mode "flat": GradSync(overlap=False), one all-reduce after backward;
     mode "torch": DistributedDataParallel through wrap_ddp."""
     from medmamba_amd import modules as M
     for name in ("selective_scan_fn", "cross_scan_fn", "shuffle_residual", "dwconv_silu_cross", "ss2d_core", "ss2d_conv_core",
@@ -75,6 +81,10 @@ def test_ddp_gradients_match_single_process(tmp_path, monkeypatch, mode):
     r1 = torch.load(tmp_path / "r1.pt", weights_only=True)
     for k in r0["grads"]:
         assert torch.equal(r0["grads"][k], r1["grads"][k]), k          # all-reduced: identical on both ranks
+    if mode == "bucketed":             # two stages -> two buckets; the last stage's went out DURING backward, in both passes
+        assert r0["nbuckets"] == 2 and r0["stats"] == [dict(buckets=2, early=1)] * 2 == r1["stats"], r0["stats"]
+    elif mode == "flat":
+        assert r0["nbuckets"] == 1 and r0["stats"] == [dict(buckets=1, early=0)] * 2
     net = _build_model()
     g = torch.Generator().manual_seed(100)
     x = torch.randn(4, 3, 16, 16, generator=g)

@@ -35,7 +35,7 @@ def _worker(rank, world, port, outdir, mode="flat"):
     if mode == "torch":                             # DistributedDataParallel (MM_DDP=torch): bucketed, overlapped with backward
         model, sync = wrap_ddp(net, dev, bucket_cap_mb=1), None      # small buckets: several all-reduces start mid-backward
     else:
-        model, sync = net, GradSync(net)
+        model, sync = net, GradSync(net, overlap=(mode == "bucketed"), timing=True)
     offset_device_rng(rank, 7)                      # per-rank device RNG (DropPath masks) after the replicas are identical
     draw = torch.rand(8, device=dev).cpu()
     opt = torch.optim.AdamW(net.parameters(), lr=1e-3, fused=True)
@@ -52,15 +52,20 @@ def _worker(rank, world, port, outdir, mode="flat"):
         opt.step()
         losses.append(float(loss))
     torch.cuda.synchronize()
+    if sync is not None:
+        assert sync.stats == (dict(buckets=4, early=3) if mode == "bucketed" else dict(buckets=1, early=0)), sync.stats
+        assert sync.allreduce_ms() > 0.0
     torch.save(dict(params={k: p.detach().cpu() for k, p in net.named_parameters()}, losses=losses, draw=draw,
                     grads={k: p.grad.detach().cpu() for k, p in net.named_parameters()}), os.path.join(outdir, f"r{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["flat", "torch"])
+@pytest.mark.parametrize("mode", ["bucketed", "flat", "torch"])
 def test_two_ranks_on_one_gpu_stay_identical(tmp_path, mode):
-    """mode "flat": GradSync (bench.py's default); mode "torch": wrap_ddp = DistributedDataParallel on HIP tensors with the
+    """mode "bucketed": GradSync as bench.py uses it — per-stage buckets whose all-reduce starts at the stage boundary inside
+    backward, while gradients of conv-branch parameters are still being produced on the side stream; mode "flat": one all-reduce
+    after backward; mode "torch": wrap_ddp = DistributedDataParallel on HIP tensors with the
     two-stream block schedule (gradients of conv-branch parameters are produced on the side stream while buckets are being
     reduced).  Same assertions: bitwise identical gradients and parameters on both ranks."""
     world, port = 2, _free_port()

@@ -30,6 +30,25 @@ def _oracle_logits(net, x, pick, depths):
         return R.vssm_forward(sd, x[pick].cpu(), depths, c_selective_scan_fn, training=False).numpy()
 
 
+def _oracle_train_pass(net, x, y, depths):
+    """Loss and every parameter gradient of ONE training-mode pass (BatchNorm batch statistics over exactly this batch,
+    MedMamba.py:338-346; forward + CE + backward = train.py:277-286) through the CPU oracle: oracle.model_ref (pinned by the
+    reference-generated fixtures) + the C scan, on the host cores."""
+    import os
+    from oracle import model_ref as R
+    from oracle.scan_ref import _lib as _olib, build_c_oracle, c_selective_scan_fn
+    build_c_oracle()
+    cores = max(1, min(16, len(os.sched_getaffinity(0))))
+    torch.set_num_threads(cores)
+    _olib().oracle_set_threads(cores)
+    p = {k: (v.detach().cpu().clone().requires_grad_() if v.dtype.is_floating_point and "running" not in k else v.detach().cpu().clone())
+         for k, v in net.state_dict().items()}
+    loss = torch.nn.functional.cross_entropy(R.vssm_forward(p, x.cpu(), depths, c_selective_scan_fn, training=True), y.cpu())
+    loss.backward()
+    names = {k for k, _ in net.named_parameters()}
+    return float(loss.detach()), {k: v.grad for k, v in p.items() if k in names}
+
+
 def _train_pass(net, x, y):
     net.zero_grad(set_to_none=True)
     loss = torch.nn.functional.cross_entropy(net(x), y)
@@ -123,6 +142,47 @@ def test_config3_S_batch64_full_size(monkeypatch):
     assert p4["ns"] == 4, p4
     f1 = _plan(64, 4, 96, 3136, backward=False)
     assert f1["vec"] == 1 and f1["ns"] in (2, 4), f1
+
+
+def test_config3_training_step_loss_and_gradients_match_the_oracle():
+    """the full-size TRAINING pass against the oracle itself — all 64 images of config 3 in train mode (BatchNorm
+    statistics over the same 64 images), loss and every parameter gradient, DropPath off.  The oracle needs ~20-40 s of 16 host
+    cores for this once (bench.py's cpu_baseline runs 32 images in ~7 s)."""
+    from medmamba_amd.modules import VSSM, MEDMAMBA_CONFIGS
+    cfg = MEDMAMBA_CONFIGS["S"]
+    torch.manual_seed(42)
+    net = VSSM(num_classes=6, drop_path_rate=0.0, **cfg).to(DEV).train()
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(64, 3, 224, 224, generator=g)
+    y = torch.randint(0, 6, (64,), generator=g)
+    sd0 = {k: v.detach().clone() for k, v in net.state_dict().items()}        # running statistics before the pass
+    want_loss, want = _oracle_train_pass(net, x, y, cfg["depths"])
+    net.load_state_dict(sd0)
+    loss, got = _train_pass(net, x.to(DEV), y.to(DEV))
+    assert abs(loss - want_loss) <= 1e-5 * abs(want_loss), (loss, want_loss)
+    assert set(got) == set(want)
+    worst = _compare_grads({k: v.to(DEV) for k, v in want.items()}, got, "HIP step vs oracle, config 3", l2_tol=3e-3, max_tol=2e-2)
+    print("config 3 worst gradient deviation from the oracle (l2 rel, tensor):", worst)
+
+
+def test_config5_training_step_matches_the_oracle_at_8_images():
+    """Config 5's shapes (MedMamba-B, 384 x 384: L = 9216 / 2304 / 576 / 144, 128 ... 1024 channels) at a batch the host can afford:
+    8 images in train mode against the oracle — loss and every parameter gradient.  The launch plans at L = 9216 are those of
+    the 32-image configuration except for the wave count."""
+    from medmamba_amd.modules import VSSM, MEDMAMBA_CONFIGS
+    cfg = MEDMAMBA_CONFIGS["B"]
+    torch.manual_seed(42)
+    net = VSSM(num_classes=6, drop_path_rate=0.0, **cfg).to(DEV).train()
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(8, 3, 384, 384, generator=g)
+    y = torch.randint(0, 6, (8,), generator=g)
+    sd0 = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    want_loss, want = _oracle_train_pass(net, x, y, cfg["depths"])
+    net.load_state_dict(sd0)
+    loss, got = _train_pass(net, x.to(DEV), y.to(DEV))
+    assert abs(loss - want_loss) <= 1e-5 * abs(want_loss), (loss, want_loss)
+    worst = _compare_grads({k: v.to(DEV) for k, v in want.items()}, got, "HIP step vs oracle, config 5 shapes", l2_tol=3e-3, max_tol=2e-2)
+    print("config 5 (8 images) worst gradient deviation from the oracle (l2 rel, tensor):", worst)
 
 
 def test_config5_B_batch32_384_full_size():

@@ -33,6 +33,17 @@ def main():
             wg = "x".join(r.get(k, "?") for k in ("Workgroup_Size_X", "Workgroup_Size_Y", "Workgroup_Size_Z"))
             print(f"\nq{q} +{(int(r['Start_Timestamp']) - t0) / 1e6:8.3f} ms  {dur(r):9.1f} us  grid {grid} wg {wg} lds {r.get('LDS_Block_Size', '?')} "
                   f"vgpr {r.get('VGPR_Count', '?')}  {short(r['Kernel_Name'])}")
+            # kernels of the OTHER queues that were running during this dispatch (overlap in us): a small kernel that shares the chip
+            # with a long one waits for wave slots, and its "duration" is mostly the other kernel's
+            s0, e0 = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+            for q2, lst2 in sorted(byq.items()):
+                if q2 == q:
+                    continue
+                for o in lst2:
+                    ov = min(e0, int(o["End_Timestamp"])) - max(s0, int(o["Start_Timestamp"]))
+                    if ov > 0.2 * (e0 - s0):
+                        print(f"      beside q{q2} {ov / 1e3:9.1f} us of {dur(o):9.1f} us  grid {o.get('Grid_Size_X', '?')} wg {o.get('Workgroup_Size_X', '?')} "
+                              f"{short(o['Kernel_Name'])}")
             for j in range(max(0, i - ctx), min(len(lst), i + ctx + 1)):
                 if j != i:
                     print(f"      {'before' if j < i else 'after '} {dur(lst[j]):9.1f} us  {short(lst[j]['Kernel_Name'])}")

@@ -11,7 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 typedef float v2f __attribute__((ext_vector_type(2)));
-constexpr int kTile = 64, kTS = 68, kBCS = 20, QL = 16;
+constexpr int kTS = 68, kBCS = 20;
 constexpr float kLog2e = 1.4426950408889634f;
 
 template <int CTRL>
@@ -21,7 +21,9 @@ __device__ __forceinline__ float dpp_f(float v) {
 __device__ __forceinline__ float f4get(const float4& v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
 
 // ------------------------------------------------------------------------------------------------ P (the shipped form)
+template <int kTile>      // 64: the long-sequence form; 32: the LEAN form (half the LDS per wave: 4 waves per SIMD fit)
 __global__ __launch_bounds__(64) void loop_P(float* out, const float* in, int iters) {
+  constexpr int QL = kTile / 4;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* s_dl = smem; float* s_du = smem + 16 * kTS; float* s_bc = smem + 2 * 16 * kTS;
   const int lane = threadIdx.x;
@@ -79,12 +81,12 @@ __global__ __launch_bounds__(64) void loop_P(float* out, const float* in, int it
   };
   for (int it = 0; it < iters; ++it) {
     Ops opA = load_ops(0);
-    for (int tg = 0; tg < 16; tg += 2) {
+    for (int tg = 0; tg < QL; tg += 2) {
       Ops opB = load_ops(tg + 1);
       __builtin_amdgcn_sched_barrier(0);
       compute(opA, tg);
       __builtin_amdgcn_sched_barrier(0);
-      opA = load_ops(tg + 2 < 16 ? tg + 2 : 15);
+      opA = load_ops(tg + 2 < QL ? tg + 2 : QL - 1);
       __builtin_amdgcn_sched_barrier(0);
       compute(opB, tg + 1);
       __builtin_amdgcn_sched_barrier(0);
@@ -126,11 +128,13 @@ __device__ __forceinline__ float mul_sel(int s, float b, float m) {
 template <bool PACKED>
 __global__ __launch_bounds__(64) void loop_D(float* out, const float* in, int iters) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* s_dl = smem; float* s_du = smem + 16 * kTS; float* s_y = smem + 2 * 16 * kTS; float* s_b = smem + 3 * 16 * kTS;
-  float* s_c = s_b + 16 * kTS;
+  // dl, du tiles as in the kernel (y overwrites du in place); the B / C registers are loaded from a small [16][64] table each
+  // (in the kernel they come from global memory / L2 by buffer_load_dword: no LDS at all): 12.9 KB per wave, 12 waves per CU fit
+  float* s_dl = smem; float* s_du = smem + 16 * kTS; float* s_y = s_du; float* s_b = smem + 2 * 16 * kTS;
+  float* s_c = s_b + 16 * 16;
   const int lane = threadIdx.x;
   for (int i = lane; i < 2 * 16 * kTS; i += 64) smem[i] = 0.01f + 0.05f * in[i & 1023];
-  for (int i = lane; i < 2 * 16 * kTS; i += 64) s_b[i] = in[(i * 7) & 1023] - 0.5f;
+  for (int i = lane; i < 2 * 16 * 16; i += 64) s_b[i] = in[(i * 7) & 1023] - 0.5f;
   __syncthreads();
   const int g = lane / 16, c = lane % 16;
   float A2[4], x[4];
@@ -140,8 +144,8 @@ __global__ __launch_bounds__(64) void loop_D(float* out, const float* in, int it
   auto load_bc = [&](int blk, float (&Bq)[4], float (&Cq)[4]) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      Bq[j] = s_b[(4 * g + j) * kTS + 16 * blk + c];
-      Cq[j] = s_c[(4 * g + j) * kTS + 16 * blk + c];
+      Bq[j] = s_b[(4 * g + j) * 16 + ((c + blk) & 15)];
+      Cq[j] = s_c[(4 * g + j) * 16 + ((c + 3 * blk) & 15)];
     }
   };
   auto block16 = [&](int blk, const float (&Bq)[4], const float (&Cq)[4]) {
@@ -233,9 +237,89 @@ __global__ __launch_bounds__(64) void loop_D(float* out, const float* in, int it
   out[blockIdx.x * 64 + lane] = acc + x[0] + x[1] + x[2] + x[3];
 }
 
+
+// ---- per-instruction rates: R independent chains of one instruction form, per waves/SIMD
+enum { I_FMA, I_EXP, I_PKFMA, I_PKMUL, I_FMAC_DPP, I_MIX, I_SWAP32, I_MIXPK };
+template <int KIND>
+__global__ __launch_bounds__(64) void rate_k(float* out, float seed, int iters) {
+  float a[8]; v2f pa[8];
+  for (int j = 0; j < 8; ++j) { a[j] = seed * (j + 1) + threadIdx.x * 1e-6f; pa[j] = (v2f){a[j], a[j] * 0.5f}; }
+  const float b = 0.999f, c = 1e-3f; const v2f pb = {0.999f, 0.998f}, pc = {1e-3f, 2e-3f};
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if constexpr (KIND == I_FMA) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[j]) : "v"(b), "v"(c));
+      } else if constexpr (KIND == I_EXP) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) asm volatile("v_exp_f32 %0, %0" : "+v"(a[j]));
+      } else if constexpr (KIND == I_PKFMA) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(pa[j]) : "v"(pb), "v"(pc));
+      } else if constexpr (KIND == I_PKMUL) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(pa[j]) : "v"(pb));
+      } else if constexpr (KIND == I_FMAC_DPP) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) asm volatile("v_fmac_f32_dpp %0, %1, %2 row_newbcast:5 row_mask:0xf bank_mask:0xf" : "+v"(a[j]) : "v"(b), "v"(c));
+      } else if constexpr (KIND == I_MIX) {      // the unpacked recurrence mix: 2 exp + 2 mul + 2 mul + 2 fma + 2 fma per 2 states
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) {
+          asm volatile("v_exp_f32 %0, %0" : "+v"(a[j]));
+          asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[j + 1]) : "v"(b));
+          asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[j + 1]) : "v"(b), "v"(c));
+          asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[j + 1]) : "v"(b));
+          asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[j + 1]) : "v"(b), "v"(c));
+        }
+      } else if constexpr (KIND == I_MIXPK) {    // packed mix: 2 exp + pk_mul + pk_mul + pk_fma + pk_fma per 2 states
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) {
+          asm volatile("v_exp_f32 %0, %0" : "+v"(a[j]));
+          asm volatile("v_exp_f32 %0, %0" : "+v"(a[j + 1]));
+          asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(pa[j]) : "v"(pb));
+          asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(pa[j + 1]) : "v"(pb));
+          asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(pa[j]) : "v"(pb), "v"(pc));
+          asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(pa[j + 1]) : "v"(pb), "v"(pc));
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(a[j]), "+v"(a[j + 1]));
+      }
+    }
+  }
+  float s = 0; for (int j = 0; j < 8; ++j) s += a[j] + pa[j].x + pa[j].y;
+  out[blockIdx.x * 64 + threadIdx.x] = s;
+}
+template <int KIND>
+void rate(const char* name, int instr_per_iter, float* d) {
+  const int iters = 2048;
+  for (int wq = 4; wq <= 16; wq *= 2) {
+    const int blocks = 256 * wq;
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    hipLaunchKernelGGL(rate_k<KIND>, dim3(blocks), dim3(64), 0, 0, d, 0.5f, iters);
+    (void)hipDeviceSynchronize(); (void)hipEventRecord(e0);
+    for (int r = 0; r < 3; ++r) hipLaunchKernelGGL(rate_k<KIND>, dim3(blocks), dim3(64), 0, 0, d, 0.5f, iters);
+    (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1); ms /= 3;
+    printf("rate %-22s waves/SIMD %d: %6.2f ns per instruction per SIMD (%5.2f cycles at 2.1 GHz)\n", name, wq / 4,
+           ms * 1e6 / ((double)iters * instr_per_iter * (wq / 4)), ms * 1e6 / ((double)iters * instr_per_iter * (wq / 4)) * 2.1);
+  }
+}
+void instr_rates(float* d) {
+  rate<I_FMA>("v_fma_f32", 32, d);
+  rate<I_EXP>("v_exp_f32", 32, d);
+  rate<I_PKFMA>("v_pk_fma_f32", 32, d);
+  rate<I_PKMUL>("v_pk_mul_f32", 32, d);
+  rate<I_FMAC_DPP>("v_fmac_f32_dpp newbcast", 32, d);
+  rate<I_MIX>("mix 1exp+2mul+2fma", 80, d);
+  rate<I_MIXPK>("mix 2exp+2pkmul+2pkfma", 96, d);
+  rate<I_SWAP32>("v_permlane32_swap", 16, d);
+}
+
 template <typename K>
-void run(const char* name, K kern, size_t lds, float* d_out, const float* d_in) {
-  const int iters = 200;      // x 64 steps
+void run(const char* name, K kern, size_t lds, float* d_out, const float* d_in, int tile = 64) {
+  const int iters = 200 * 64 / tile;      // x tile steps = 12800 steps
   (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   for (int wq = 4; wq <= 16; wq += (wq < 8 ? 2 : 4)) {     // waves per SIMD x 4: 1, 1.5, 2, 3, 4
     const int blocks = 256 * wq;
@@ -246,10 +330,10 @@ void run(const char* name, K kern, size_t lds, float* d_out, const float* d_in) 
     for (int r = 0; r < 3; ++r) hipLaunchKernelGGL(kern, dim3(blocks), dim3(64), lds, 0, d_out, d_in, iters);
     (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
     float ms; (void)hipEventElapsedTime(&ms, e0, e1); ms /= 3;
-    const double ns_step = ms * 1e6 / (iters * 64.0);
+    const double ns_step = ms * 1e6 / 12800.0;
     // a launch of W = blocks wavefronts over 1024 SIMDs; all resident at once here, so the kernel time is one wave's serial time
-    printf("%-3s waves/SIMD %.1f: %7.3f ms  %6.1f ns per step and wave  | chip rate %.2f G state-steps/s | 3136 steps: %.3f ms\n", name, wq / 4.0, ms,
-           ns_step, blocks * 256.0 * iters * 64 / ms / 1e6, ns_step * 3136 / 1e6);
+    printf("%-3s LDS %5.1f KB waves/SIMD %.1f: %7.3f ms  %6.1f ns per step and wave, %5.1f ns per wave-step of the SIMD | chip %.2f T state-steps/s\n",
+           name, lds / 1024.0, wq / 4.0, ms, ns_step, ns_step / (wq / 4.0), blocks * 256.0 * 12800 / ms / 1e9);
   }
 }
 
@@ -259,8 +343,10 @@ int main() {
   (void)hipMalloc(&d_in, 1024 * sizeof(float));
   float h[1024]; for (int i = 0; i < 1024; ++i) h[i] = (float)(rand() & 0xffff) / 65536.f;
   (void)hipMemcpy(d_in, h, sizeof(h), hipMemcpyHostToDevice);
-  run("P", loop_P, sizeof(float) * (2 * 16 * kTS + 2 * kTile * kBCS), d_out, d_in);
-  run("D", loop_D<false>, sizeof(float) * (5 * 16 * kTS), d_out, d_in);
-  run("D3", loop_D<true>, sizeof(float) * (5 * 16 * kTS), d_out, d_in);
+  run("P64", loop_P<64>, sizeof(float) * (2 * 16 * kTS + 2 * 64 * kBCS), d_out, d_in, 64);
+  run("P32", loop_P<32>, sizeof(float) * (2 * 16 * kTS + 2 * 32 * kBCS), d_out, d_in, 32);
+  run("D", loop_D<false>, sizeof(float) * (2 * 16 * kTS + 2 * 16 * 16), d_out, d_in);
+  run("D3", loop_D<true>, sizeof(float) * (2 * 16 * kTS + 2 * 16 * 16), d_out, d_in);
+  instr_rates(d_out);
   return 0;
 }
