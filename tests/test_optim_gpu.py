@@ -114,8 +114,11 @@ def test_hip_adamw_step_is_seen_by_the_version_keyed_inference_caches():
                 if isinstance(m, SS_Conv_SSM):
                     m._fold_cache = None
             fresh = net(x)
-        assert not torch.equal(before, after)
-        assert torch.equal(after, fresh), f"stale folded constants after optimizer step {step}"
+        # a step with lr 5e-2 moves the logits by O(1); a forward on stale folded constants would sit between the two.  (Not
+        # bitwise: the eval forward's library GEMMs / convolutions are not guaranteed run-to-run identical.)
+        moved = float((before - after).abs().max())
+        stale = float((after - fresh).abs().max())
+        assert moved > 1e-2 and stale <= 1e-5 * max(1.0, float(fresh.abs().max())), (step, moved, stale)
     assert opt._plans and opt._plans[0][5] is not None, "the HIP update did not engage"
     assert all(p._version >= v + 3 for p, v in zip(params, v0))
     n = graphed.captures
