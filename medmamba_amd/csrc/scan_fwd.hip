@@ -664,6 +664,264 @@ __global__ __launch_bounds__(256) void scan_fwd_rows_kernel(const FwdParams p) {
   store_tile((p.ntiles - 1) * kT);
 }
 
+
+// ======================================================================================================================
+// Workgroup-cooperative form for LONG sequences with FEW sequences (round 4; the 56x56 stage of T / S, the 96x96 stage of B).
+// There the general kernel has 1536 wavefronts of 4 states per lane for 1024 SIMDs: half of the SIMDs run two wavefronts (95 ns
+// per step for the pair), half run one (62 ns per step, then idle) — and every wavefront stages the whole B / C tile for itself.
+// Here a workgroup takes one (batch, direction) (or half of its channels): W wavefronts x 8 channels, lane = (state group
+// g = lane / 8, channel c = lane % 8), 2 states per lane -> 3072 wavefronts for that stage, three per SIMD on every SIMD (one
+// 12-wave workgroup per CU at 64 images).  What makes 2 states per lane affordable, which it was not in the general kernel:
+//   * B / C are staged ONCE per workgroup (plain coalesced b128 stores, [state][position] rows, double buffered: one barrier
+//     per 64-step tile) instead of once per wavefront with a transposing store;
+//   * the recurrence reads them with ONE ds_read_b32 per state and 4 steps (lane c of a quad holds step c % 4) and the FMAs pick
+//     the step through DPP quad_perm:[s,s,s,s]: 1 LDS read per step and wave instead of 2.5;
+//   * y: three permlane swaps + one row_ror:8 add per 4 steps sum the 8 state groups.
+template <int S> __device__ __forceinline__ void fmac_q(float& acc, float b, float m) {      // acc += (lane S of b's quad) * m
+  asm("v_fmac_f32_dpp %0, %1, %2 quad_perm:[%3,%3,%3,%3] row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(b), "v"(m), "n"(S));
+}
+template <int S> __device__ __forceinline__ float mul_q(float b, float m) {
+  float r;
+  asm("v_mul_f32_dpp %0, %1, %2 quad_perm:[%3,%3,%3,%3] row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(b), "v"(m), "n"(S));
+  return r;
+}
+__device__ __forceinline__ void fmac_qsel(int s, float& acc, float b, float m) {
+  switch (s) { case 0: fmac_q<0>(acc, b, m); break; case 1: fmac_q<1>(acc, b, m); break; case 2: fmac_q<2>(acc, b, m); break;
+               default: fmac_q<3>(acc, b, m); break; }
+}
+__device__ __forceinline__ float mul_qsel(int s, float b, float m) {
+  switch (s) { case 0: return mul_q<0>(b, m); case 1: return mul_q<1>(b, m); case 2: return mul_q<2>(b, m); default: return mul_q<3>(b, m); }
+}
+
+constexpr int kWgT = 64, kWgTS = kWgT + 4, kWgCH = 8;
+constexpr int kWgBC = 2 * 2 * kNState * kWgTS;                      // floats of the double-buffered B / C tile
+constexpr int kWgWave = 2 * kWgCH * kWgTS;                          // floats per wave: delta', delta'*u / y
+
+template <bool SP>
+__global__ __launch_bounds__(1024) void scan_fwd_wg_kernel(const FwdParams p) {
+  constexpr int CH = kWgCH, kT = kWgT, kTS = kWgTS, QL = kT / 4, RPI = kWave / QL, NLD = CH / RPI;   // 16 lanes per row, 4 rows, 2 loads
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nthreads = blockDim.x, nwv = nthreads >> 6;
+  int blk = blockIdx.x;
+  const int nblk = gridDim.x;
+  if ((nblk & 7) == 0) blk = (blk & 7) * (nblk >> 3) + (blk >> 3);      // workgroups of one (batch, direction) meet in one XCD's L2
+  const int cwb = blk % p.wpg;                                          // p.wpg = workgroups per (batch, direction) here
+  const int bk = blk / p.wpg;
+  if (bk >= p.batch * p.G) return;                                      // (whole workgroup)
+  const int grp = bk % p.G, b = bk / p.G;
+  const int ugrp = p.ug < p.G ? (int)((p.u_map >> (4 * grp)) & 15) : grp;
+  const bool rev = grp < 32 && ((p.rev_mask >> grp) & 1);
+
+  float* sBC = smem;                                   // [2 buf][B, C][16 states][kTS]
+  float* wl = smem + kWgBC + wave * kWgWave;
+  float* s_dl = wl;                                    // [CH][kTS] delta'
+  float* s_du = wl + CH * kTS;                         // [CH][kTS] delta'*u, then y (in place)
+
+  // ---- recurrence identity: lane = (g, c): states 2g, 2g+1 of channel c; a quad = 4 channels of one state group
+  const int g = lane >> 3, c = lane & 7, qi = lane & 3;
+  const int ch0 = (cwb * nwv + wave) * CH;             // first channel (inside the group) of this wave
+  const int hc = ch0 + c;
+  const bool cvalid = hc < p.H;
+  const bool wactive = ch0 < p.H;                      // a wave beyond the last channel only helps staging B / C
+  const int d = grp * p.H + (cvalid ? hc : 0);
+  v2f A01, x01 = {0.f, 0.f};
+  {
+    const float* Ad = p.A + (int64_t)d * kNState + 2 * g;
+    A01 = (v2f){Ad[0] * kLog2e, Ad[1] * kLog2e};
+  }
+  // ---- staging identity of u, delta, out: row r of a 4-row group, float4 column q
+  const int r = lane / QL, q = lane % QL;
+  const int d0 = grp * p.H + ch0;
+  const int d0u = ugrp * p.H + ch0;
+  const int nrw = min(CH, p.H - ch0);
+  const rsrc_t ru = make_rsrc(p.u + b * p.u_sb + d0u * p.u_sd, ((int64_t)(nrw - 1) * p.u_sd + p.L) * 4);
+  const rsrc_t rd = make_rsrc(p.delta + b * p.d_sb + d0 * p.d_sd, ((int64_t)(nrw - 1) * p.d_sd + p.L) * 4);
+  const rsrc_t ro = make_rsrc(p.out + ((int64_t)b * p.dim + d0) * p.L, (int64_t)nrw * p.L * 4);
+  const rsrc_t rB = make_rsrc(p.B + b * p.B_sb + grp * p.B_sg, ((int64_t)(kNState - 1) * p.B_sn + p.L) * 4);
+  const rsrc_t rC = make_rsrc(p.C + b * p.C_sb + grp * p.C_sg, ((int64_t)(kNState - 1) * p.C_sn + p.L) * 4);
+  float Dv[NLD], bv[NLD];
+  bool rvalid[NLD];
+  int uoff[NLD], doff[NLD], ooff[NLD];
+#pragma unroll
+  for (int i = 0; i < NLD; ++i) {
+    rvalid[i] = ch0 + r + RPI * i < p.H;
+    const int dd = grp * p.H + (rvalid[i] ? ch0 + r + RPI * i : 0);
+    Dv[i] = p.D ? p.D[dd] : 0.f;
+    bv[i] = p.bias ? p.bias[dd] : 0.f;
+    uoff[i] = (int)((r + RPI * i) * p.u_sd) * 4;
+    doff[i] = (int)((r + RPI * i) * p.d_sd) * 4;
+    ooff[i] = ((r + RPI * i) * p.L) * 4;
+  }
+  // ---- staging identity of the shared B / C tile: 2 x 16 rows x 16 quads = 512 quads over the workgroup's threads (>= 256)
+  constexpr int NBCQ = 2;
+  int bcoff[NBCQ], bclds[NBCQ];
+  bool bcok[NBCQ], bcisC[NBCQ];
+#pragma unroll
+  for (int j = 0; j < NBCQ; ++j) {
+    const int k = tid + j * nthreads;
+    bcok[j] = k < 512;
+    const int isC = (k >> 8) & 1, n = (k >> 4) & 15;
+    bcisC[j] = isC;
+    bcoff[j] = (int)(n * (isC ? p.C_sn : p.B_sn)) * 4;
+    const int qq = k & 15;
+    bclds[j] = (isC * kNState + n) * kTS + 4 * (rev ? QL - 1 - qq : qq);
+  }
+  const int qbc = tid & 15;                            // (k & 15 == tid & 15 for both j: nthreads is a multiple of 64)
+
+  float4 pu[NLD], pd[NLD], pbc[NBCQ];
+  auto issue_loads = [&](int t0) {
+    const int t = t0 + 4 * q;
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      pu[i] = load_quad<true, true>(ru, uoff[i], t, p.L, rev, rvalid[i]);
+      pd[i] = load_quad<true, true>(rd, doff[i], t, p.L, rev, rvalid[i]);
+    }
+#pragma unroll
+    for (int j = 0; j < NBCQ; ++j)
+      pbc[j] = load_quad<true, true>(bcisC[j] ? rC : rB, bcoff[j], t0 + 4 * qbc, p.L, rev, bcok[j]);
+  };
+  const int qc = rev ? QL - 1 - q : q;                 // a reversed tile lies mirrored in LDS (quads in memory order)
+  float4 yreg[NLD];
+  auto store_tile = [&](int t0) {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) store_quad<true, true>(ro, ooff[i], t0 + 4 * q, p.L, rev, rvalid[i], yreg[i]);
+  };
+  const int row = lane >> 4;
+  const int ystep = (row & 1) * 2 + (row >> 1);        // rows 0..3 end with the sums of steps 0, 2, 1, 3 of a group (see below)
+
+  issue_loads(0);
+  for (int tile = 0; tile < p.ntiles; ++tile) {
+    const int t0 = tile * kT;
+    float* sB = sBC + (tile & 1) * (2 * kNState * kTS);
+    // ---- phase 1: registers -> LDS
+    float4 uD[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int t = t0 + 4 * q;
+      float4 dl, du;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float raw = f4get(pd[i], e) + bv[i];
+        float v = SP ? softplus_f(raw) : raw;
+        v = (rvalid[i] && t < p.L) ? v : 0.f;
+        (&dl.x)[e] = v;
+        (&du.x)[e] = v * f4get(pu[i], e);
+      }
+      uD[i] = make_float4(pu[i].x * Dv[i], pu[i].y * Dv[i], pu[i].z * Dv[i], pu[i].w * Dv[i]);
+      const int off = (RPI * i + r) * kTS + 4 * qc;
+      *reinterpret_cast<float4*>(s_dl + off) = dl;
+      *reinterpret_cast<float4*>(s_du + off) = du;
+    }
+#pragma unroll
+    for (int j = 0; j < NBCQ; ++j)
+      if (bcok[j]) *reinterpret_cast<float4*>(sB + bclds[j]) = pbc[j];
+    if (tile > 0) store_tile(t0 - kT);
+    if (tile + 1 < p.ntiles) issue_loads(t0 + kT);
+    // the B / C tile of this step is complete; the other buffer was last read one tile ago, before every wave's previous barrier
+    __syncthreads();
+
+    // ---- phase 2: the recurrence
+    const int tlen = min(kT, p.L - t0);
+    const int ngroups = wactive ? (tlen + 3) >> 2 : 0;
+    auto phase2 = [&](auto rvtag) {
+      constexpr bool RV = decltype(rvtag)::value;
+      struct Ops { float4 dl4, du4; float B0, B1, C0, C1; };
+      const float* sBl = sB + (2 * g) * kTS;                   // this lane's two B rows; C rows follow 16 rows later
+      auto load_ops = [&](int tg) {
+        Ops o;
+        const int col = RV ? QL - 1 - tg : tg;
+        o.dl4 = *reinterpret_cast<const float4*>(s_dl + c * kTS + 4 * col);
+        o.du4 = *reinterpret_cast<const float4*>(s_du + c * kTS + 4 * col);
+        const int pos = RV ? kT - 1 - (4 * tg + qi) : 4 * tg + qi;      // lane qi of the quad holds step qi of the group
+        o.B0 = sBl[pos]; o.B1 = sBl[kTS + pos];
+        o.C0 = sBl[kNState * kTS + pos]; o.C1 = sBl[(kNState + 1) * kTS + pos];
+        return o;
+      };
+      auto at = [](const float4& v, int e) { return f4get(v, RV ? 3 - e : e); };
+      auto compute = [&](const Ops& o, int tg) {
+        v2f a[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const v2f pw = A01 * at(o.dl4, e);
+          a[e] = (v2f){__builtin_amdgcn_exp2f(pw.x), __builtin_amdgcn_exp2f(pw.y)};
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        float y[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float du = at(o.du4, e);
+          const v2f t = a[e] * x01;
+          float tl = t.x, th = t.y;
+          fmac_qsel(e, tl, o.B0, du);
+          fmac_qsel(e, th, o.B1, du);
+          float yy = mul_qsel(e, o.C0, tl);
+          fmac_qsel(e, yy, o.C1, th);
+          x01 = (v2f){tl, th};
+          y[e] = yy;
+        }
+        // sum over the 8 state groups (lane bits 5, 4, 3): swap32 + add, swap16 + add leave the sums of steps 0, 2, 1, 3 in rows
+        // 0..3 (each still split over the two halves of its row), row_ror:8 + add joins the halves
+        const auto r01 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, y[0]), __builtin_bit_cast(unsigned, y[1]), false, false);
+        const unsigned u0 = r01[0], u1 = r01[1];
+        const float s01 = __builtin_bit_cast(float, u0) + __builtin_bit_cast(float, u1);
+        const auto r23 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, y[2]), __builtin_bit_cast(unsigned, y[3]), false, false);
+        const unsigned u2 = r23[0], u3 = r23[1];
+        const float s23 = __builtin_bit_cast(float, u2) + __builtin_bit_cast(float, u3);
+        const auto rr = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, s01), __builtin_bit_cast(unsigned, s23), false, false);
+        const unsigned w0 = rr[0], w1 = rr[1];
+        float yt = __builtin_bit_cast(float, w0) + __builtin_bit_cast(float, w1);
+        yt += dpp_f<DPP_ROW_ROR8>(yt);
+        const int tpos = 4 * tg + ystep;
+        s_du[c * kTS + (RV ? kT - 1 - tpos : tpos)] = yt;              // (both halves of a row store the same value)
+        if (p.x_chk != nullptr && ((tg & 3) == 3 || tg == ngroups - 1)) {
+          // checkpoint (batch, chunk, dim, 16): 8 B per lane, the wave's 8 channels x 16 states are one 512-B run (measured equal
+          // to 16-B pieces re-ordered through LDS: 0.369 vs 0.372 ms at the 56x56 stage)
+          if (cvalid)
+            *reinterpret_cast<float2*>(p.x_chk + (((int64_t)b * p.nchk + (t0 >> 4) + (tg >> 2)) * p.dim + d) * kNState + 2 * g) =
+                make_float2(x01.x, x01.y);
+        }
+      };
+      if (ngroups > 0) {
+        Ops opA = load_ops(0);
+        for (int tg = 0; tg < ngroups; tg += 2) {
+          Ops opB = load_ops(min(tg + 1, ngroups - 1));
+          __builtin_amdgcn_sched_barrier(0);
+          compute(opA, tg);
+          __builtin_amdgcn_sched_barrier(0);
+          opA = load_ops(min(tg + 2, ngroups - 1));
+          __builtin_amdgcn_sched_barrier(0);
+          if (tg + 1 < ngroups) compute(opB, tg + 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    };
+    if (rev) phase2(std::true_type{}); else phase2(std::false_type{});
+
+    // ---- phase 3: y (+ D*u) LDS -> registers (stored at the next tile's load point)
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const float4 y = *reinterpret_cast<const float4*>(s_du + (RPI * i + r) * kTS + 4 * qc);
+      yreg[i] = make_float4(y.x + uD[i].x, y.y + uD[i].y, y.z + uD[i].z, y.w + uD[i].w);
+    }
+  }
+  store_tile((p.ntiles - 1) * kT);
+}
+
+template <bool SP>
+int launch_wg(const FwdParams& p, int ncw, int nwv, hipStream_t stream) {
+  const size_t lds = sizeof(float) * (size_t)(kWgBC + nwv * kWgWave);
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute((const void*)scan_fwd_wg_kernel<SP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  FwdParams q = p;
+  q.ntiles = (p.L + kWgT - 1) / kWgT;
+  q.wpg = ncw;
+  const int nblocks = (p.batch * p.G * ncw + 7) & ~7;
+  hipLaunchKernelGGL((scan_fwd_wg_kernel<SP>), dim3(nblocks), dim3(nwv * 64), lds, stream, q);
+  return (int)hipGetLastError();
+}
+
 template <bool SP>
 int launch_rows(const FwdParams& p, int nblocks, int wpb, hipStream_t stream) {
   const size_t lds = sizeof(float) * (size_t)wpb * (2 * 16 * (64 + 4));
@@ -734,8 +992,9 @@ int scan_fwd_launch(const mm_scan_args* a, hipStream_t stream, int32_t* plan_out
   int ns = (a->variant & 0xff) ? (a->variant & 0xff) : plan_fwd_variant(a->batch, a->G, p.H, a->L);
   // variant low byte 16: the "rows" kernel (4 states per lane, B / C through DPP row broadcasts); it exists for the vector path
   // with softplus and a delta tensor (the training call) — anything else takes the general kernel with its own plan
-  const bool want_rows = ns == 16;
+  const bool want_rows = ns == 16, want_wg = ns == 32;
   if (want_rows) ns = 4;
+  if (want_wg) ns = plan_fwd_variant(a->batch, a->G, p.H, a->L);
   if (ns != 1 && ns != 2 && ns != 4) return MM_ERR_UNSUPPORTED;
   int wpb = (a->variant >> 16) & 0xff;      // waves per workgroup (tuning knob; waves never synchronise)
   if (wpb <= 0) wpb = (ns == 4 && (long)a->batch * a->dim / 16 >= 3072) ? 4 : 2;
@@ -769,6 +1028,19 @@ int scan_fwd_launch(const mm_scan_args* a, hipStream_t stream, int32_t* plan_out
   bool lean = ns == 4 && p.nwaves_total >= 3 * 1024;
   if (a->variant & (1 << 24)) lean = true;
   if (a->variant & (1 << 25)) lean = false;
+  // variant low byte 32 (or the default plan, below): the workgroup-cooperative kernel for long sequences with few sequences
+  const bool can_wg = vec && sp && a->dt_w == nullptr;
+  int wg_ncw = 0, wg_nwv = 0;
+  if (can_wg) {
+    const int tiles8 = (p.H + 7) / 8;
+    wg_ncw = (tiles8 + 15) / 16;
+    // fill the chip: at least 256 workgroups if the waves allow it (never below 4 waves per workgroup)
+    while ((long)a->batch * a->G * wg_ncw < 256 && (tiles8 + 2 * wg_ncw - 1) / (2 * wg_ncw) >= 4) wg_ncw *= 2;
+    wg_nwv = (tiles8 + wg_ncw - 1) / wg_ncw;
+    const int wv_req = (a->variant >> 16) & 0xff;   // tuning knob: waves per workgroup
+    if (wv_req >= 4 && wv_req <= 16) { wg_nwv = wv_req < tiles8 ? wv_req : tiles8; wg_ncw = (tiles8 + wg_nwv - 1) / wg_nwv; }
+    if (wg_nwv < 4) wg_nwv = 4;                     // 512 B / C quads over >= 256 threads
+  }
   const bool rows = want_rows && vec && sp && a->dt_w == nullptr;
   if (rows) {
     wpb = (a->variant >> 16) & 0xff;
@@ -779,12 +1051,20 @@ int scan_fwd_launch(const mm_scan_args* a, hipStream_t stream, int32_t* plan_out
     nblocks = ((p.nwaves_total + wpb - 1) / wpb + 7) & ~7;
     lean = false;
   }
+  // default plan: long sequences that offer fewer than 2 wavefronts of 4 states per SIMD (the 56x56 stage of T / S at 64 images:
+  // 0.43 -> 0.34 ms inference form, 0.43 -> 0.37 ms with checkpoints; the 96x96 stage of B at 32: 0.91 -> 0.74 / 0.90 -> 0.79 ms);
+  // with more sequences the general kernel's 4 states per lane win (28x28 stage: 0.163 vs 0.185 ms).  variant 32 forces it.
+  const long seq16 = (long)a->batch * a->G * p.H / 16;
+  const bool plan_wg = (a->variant & 0xff) == 0 && a->L >= 512 && seq16 >= 256 && seq16 < 2048;
+  const bool use_wg = can_wg && (want_wg || plan_wg);
+  if (use_wg) { ns = 2; wpb = wg_nwv; nblocks = (a->batch * a->G * wg_ncw + 7) & ~7; lean = false; }
   if (plan_out) {     // mm_scan_plan: report, do not launch
     plan_out[0] = ns; plan_out[1] = wpb; plan_out[2] = nblocks; plan_out[3] = vec ? 1 : 0; plan_out[4] = lean ? 1 : 0;
-    plan_out[5] = rows ? 1 : 0;
+    plan_out[5] = rows ? 1 : (use_wg ? 2 : 0);
     return MM_OK;
   }
   if (rows) return launch_rows<true>(p, nblocks, wpb, stream);
+  if (use_wg) return launch_wg<true>(p, wg_ncw, wg_nwv, stream);
   switch (ns) {
     case 1: return launch_ns<1>(p, nblocks, wpb, vec, sp, lean, stream);
     case 2: return launch_ns<2>(p, nblocks, wpb, vec, sp, lean, stream);

@@ -110,26 +110,36 @@ class FusedAdamW(torch.optim.AdamW):
         torch.autograd.graph.increment_version(h["written"])
         return True
 
+    def _torch_step(self, closure=None):
+        """torch's own step, then the version bump the inference caches rely on (SS_Conv_SSM._eval_fold, GraphedInference: keyed on
+        (data_ptr, _version)).  Measured on this build (tests/test_optim_gpu.py): after torch's fused multi-tensor update the
+        folded constants were NOT rebuilt, i.e. `_fused_adamw_` does not advance the parameters' version counters here."""
+        out = super().step(closure)
+        ps = [p for group in self.param_groups for p in group["params"]]
+        if ps:
+            torch.autograd.graph.increment_version(ps)
+        return out
+
     @torch.no_grad()
     def step(self, closure=None):
         if closure is not None or getattr(self, "grad_scale", None) is not None or getattr(self, "found_inf", None) is not None:
             self._plans = None
-            return super().step(closure)
+            return self._torch_step(closure)
         if self._plans is None:
             self._plans = self._build_plans()          # state that load_state_dict brought along: the cached path from this step on
             if self._plans is None:                    # (a resumed run then takes the same kernels as the run it continues)
-                out = super().step()                   # torch's own step: creates / validates the state
+                out = self._torch_step()               # torch's own step: creates / validates the state
                 self._plans = self._build_plans() or False
                 return out
         if self._plans is False:
-            return super().step()
+            return self._torch_step()
         all_grads = []
         for _, params, *_ in self._plans:
             grads = [p.grad for p in params]
             for g in grads:
                 if g is None:                          # a parameter without a gradient this step: torch's general path
                     self._plans = None                 # (its step counters then run apart: rebuild the lists afterwards)
-                    return super().step()
+                    return self._torch_step()
             all_grads.append(grads)
         for plan, grads in zip(self._plans, all_grads):
             group, params, exp_avgs, exp_avg_sqs, steps, hip = plan
@@ -142,6 +152,7 @@ class FusedAdamW(torch.optim.AdamW):
             torch._fused_adamw_(params, grads, exp_avgs, exp_avg_sqs, [], steps, amsgrad=False, lr=group["lr"], beta1=beta1,
                                 beta2=beta2, weight_decay=group["weight_decay"], eps=group["eps"], maximize=False,
                                 grad_scale=None, found_inf=None)
+            torch.autograd.graph.increment_version(params)
         return None
 
     def zero_grad(self, set_to_none=True):

@@ -9,7 +9,8 @@ def short(n):
     return n[:100]
 
 def main():
-    d = sys.argv[1]; nscan = int(sys.argv[2]) if len(sys.argv) > 2 else 14; top = int(sys.argv[3]) if len(sys.argv) > 3 else 45
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    d = args[0]; nscan = int(args[1]) if len(args) > 1 else 14; top = int(args[2]) if len(args) > 2 else 45
     f = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)[0]
     rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
     idx = [i for i, r in enumerate(rows) if "scan_fwd_kernel" in r["Kernel_Name"]]
@@ -35,6 +36,16 @@ def main():
     print(f"{'kernel':<102} {'calls':>6} {'total_us':>10} {'avg_us':>9} {'pct':>6}")
     for k, (n, us) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:top]:
         print(f"{k:<102} {n:>6} {us:>10.1f} {us/n:>9.2f} {100*us/busy:>6.2f}")
+    if "--per-queue" in sys.argv:
+        for qid in sorted(qs):
+            sub = collections.defaultdict(lambda: [0, 0.0])
+            for r in last:
+                if r.get("Queue_Id", "?") == qid:
+                    a = sub[short(r["Kernel_Name"])]; a[0] += 1; a[1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+            tot = sum(v[1] for v in sub.values())
+            print(f"\n# queue {qid}: {sum(v[0] for v in sub.values())} launches, {tot/1e3:.3f} ms of kernel time")
+            for k, (n, us) in sorted(sub.items(), key=lambda kv: -kv[1][1])[:30]:
+                print(f"{k:<102} {n:>6} {us:>10.1f} {us/n:>9.2f} {100*us/tot:>6.2f}")
 
 if __name__ == "__main__":
     main()
