@@ -17,7 +17,7 @@ def main():
     ctx = int(sys.argv[4]) if len(sys.argv) > 4 else 3
     f = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)[0]
     rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-    idx = [i for i, r in enumerate(rows) if "scan_fwd_kernel" in r["Kernel_Name"]]
+    idx = [i for i, r in enumerate(rows) if re.search(r"scan_fwd(_wg|_rows)?_kernel", r["Kernel_Name"])]      # all forward kernels
     last = rows[idx[-nscan]:]
     t0 = int(last[0]["Start_Timestamp"])
     dur = lambda r: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3

@@ -13,7 +13,7 @@ def main():
     d = args[0]; nscan = int(args[1]) if len(args) > 1 else 14; top = int(args[2]) if len(args) > 2 else 45
     f = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)[0]
     rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-    idx = [i for i, r in enumerate(rows) if "scan_fwd_kernel" in r["Kernel_Name"]]
+    idx = [i for i, r in enumerate(rows) if re.search(r"scan_fwd(_wg|_rows)?_kernel", r["Kernel_Name"])]      # all forward kernels
     start = idx[-nscan]
     last = rows[start:]
     t0, t1 = int(last[0]["Start_Timestamp"]), max(int(r["End_Timestamp"]) for r in last)

@@ -10,7 +10,9 @@ def per_kernel(d, counter):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] != counter:
                 continue
-            k = "scan_fwd" if "scan_fwd_kernel" in r["Kernel_Name"] else "scan_bwd" if "scan_bwd_kernel" in r["Kernel_Name"] else None
+            nm = r["Kernel_Name"]
+            k = "scan_fwd" if ("scan_fwd_kernel" in nm or "scan_fwd_wg_kernel" in nm or "scan_fwd_rows_kernel" in nm) else \
+                "scan_bwd" if "scan_bwd_kernel" in nm else None
             if k:
                 tot[k] += float(r["Counter_Value"]); n[k] += 1
     return {k: tot[k] / n[k] for k in tot}, dict(n)
@@ -24,5 +26,7 @@ out = {"note": "HBM traffic of the scan kernels inside bench.py (MedMamba-S, 64 
                "2 x stage4 per step).", "launches_counted": {"fetch": nf, "write": nw}}
 for k in ("scan_fwd", "scan_bwd"):
     out[k] = {"bytes_per_launch": round((2 * fetch[k] + write[k]) * 1024), "fetch_KB": round(fetch[k], 1), "write_KB": round(write[k], 1)}
+if len(sys.argv) > 4:
+    out["measured_at_commit"] = sys.argv[4]           # HEAD of the tree the passes ran on (the GPU box has no .git: passed in)
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out, indent=1))
