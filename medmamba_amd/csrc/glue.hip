@@ -12,6 +12,15 @@
 #include "medmamba_hip.h"
 
 namespace {
+// Ordering between the lanes of ONE wavefront through its own LDS region (one plane per wavefront kernels): LDS instructions of a
+// wave execute in order, so a later ds_read sees an earlier ds_write of any lane of the same wave — all that is needed is that the
+// compiler keeps the order.  A workgroup barrier here made the 4 independent waves of a workgroup wait for each other three times per plane.
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 using namespace mm;
 
 // grid: (ceil(P/32), ceil(C2/32), B); block 256 = 8 rows x 32 lanes
@@ -322,7 +331,7 @@ __global__ __launch_bounds__(256) void dwconv_silu_cross_fwd_small_kernel(const 
 #pragma unroll
     for (int i = 0; i < 9; ++i) k[i] = wgt[d * 9 + i];
     const float bs = bias ? bias[d] : 0.f;
-    __syncthreads();
+    wave_lds_sync();
     float* o0 = u2 + b * u_sb + d * u_sd;
     float* o1 = u2 + b * u_sb + (D + d) * u_sd;
     for (DivMod dv(lane, 64, W); dv.q < H; dv.next()) {
@@ -337,12 +346,12 @@ __global__ __launch_bounds__(256) void dwconv_silu_cross_fwd_small_kernel(const 
       if (okp) o0[i] = v;
       so[h * (W + 1) + w] = v;
     }
-    __syncthreads();
+    wave_lds_sync();
     for (DivMod dv(lane, 64, H); dv.q < W; dv.next()) {      // i = w*H + h
       const int i = dv.q * H + dv.r, w = dv.q, h = dv.r;
       if (okp) o1[i] = so[h * (W + 1) + w];
     }
-    __syncthreads();
+    wave_lds_sync();
   }
 }
 
@@ -387,7 +396,7 @@ __global__ __launch_bounds__(256) void dwconv_silu_cross_bwd_small_kernel(const 
 #pragma unroll
     for (int i = 0; i < 9; ++i) k[i] = wgt[d * 9 + i];
     const float bs = bias ? bias[d] : 0.f;
-    __syncthreads();
+    wave_lds_sync();
     float acc[10];
 #pragma unroll
     for (int i = 0; i < 10; ++i) acc[i] = 0.f;
@@ -409,7 +418,7 @@ __global__ __launch_bounds__(256) void dwconv_silu_cross_bwd_small_kernel(const 
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) acc[kh * 3 + kw] = fmaf(dp, c[kh * WP + kw], acc[kh * 3 + kw]);
     }
-    __syncthreads();
+    wave_lds_sync();
     float* dxp = dx + (int64_t)b * dx_sb + (int64_t)d * dx_sd;
     for (DivMod dv(lane, 64, W); dv.q < H; dv.next()) {
       const int i = dv.q * W + dv.r, h = dv.q, w = dv.r;
@@ -427,7 +436,7 @@ __global__ __launch_bounds__(256) void dwconv_silu_cross_bwd_small_kernel(const 
       v += __shfl_xor(v, 32);
       if (lane == 0 && okp) ws[(int64_t)pl * 10 + i] = v;
     }
-    __syncthreads();
+    wave_lds_sync();
   }
 }
 
@@ -548,7 +557,7 @@ __global__ __launch_bounds__(256) void plane_small_kernel(const float* __restric
         tile[wv][i] = in ? o2[i] + o3[i] : 0.f;
         a[j] = in ? o0[i] + o1[i] : 0.f;
       }
-      __syncthreads();
+      wave_lds_sync();
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int i = lane + 64 * j;
@@ -561,14 +570,14 @@ __global__ __launch_bounds__(256) void plane_small_kernel(const float* __restric
         const int i = lane + 64 * j;
         if (okp && i < L) tile[wv][tr[j]] = sp[i];
       }
-      __syncthreads();
+      wave_lds_sync();
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int i = lane + 64 * j;
         if (okp && i < L) t[i] = tile[wv][i];
       }
     }
-    __syncthreads();                           // the tile is rewritten by the next iteration
+    wave_lds_sync();                           // the tile is rewritten by the next iteration
   }
 }
 
