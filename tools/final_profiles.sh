@@ -30,8 +30,11 @@ python3 tools/traffic_from_pmc.py $out/pmcF $out/pmcW $out/scan_traffic.json "${
 python3 tools/pmc_summary.py $out/pmcF $out/pmcW > $out/scan_traffic_pmc.txt
 rm -rf $out/pmcF $out/pmcW
 run scan_layouts 300 env FWD_VARIANTS=0 python3 tools/bench_scan_bwd.py S 64 0
+export FWD_VARIANTS=0
 tools/prof_pmc.sh final_$tag/sq1 "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES" -- python3 tools/bench_scan_bwd.py S 64 0 0,2
-tools/prof_pmc.sh final_$tag/sq2 "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS" -- env FWD_VARIANTS=0 python3 tools/bench_scan_bwd.py S 64 0 0,2
+export FWD_VARIANTS=0       # (set here, not through `env` behind rocprofv3: the profiler has initialised the GPU by then and an exec is refused)
+tools/prof_pmc.sh final_$tag/sq2 "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS" -- python3 tools/bench_scan_bwd.py S 64 0 0,2
+unset FWD_VARIANTS
 python3 tools/pmc_summary.py $out/sq1 $out/sq2 > $out/scan_sq_counters.txt 2>&1
 rm -rf $out/sq1 $out/sq2
 run host_ops_b64 300 python3 tools/host_op_profile.py 64
