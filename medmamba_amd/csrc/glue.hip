@@ -143,6 +143,18 @@ struct DivMod {
   __device__ __forceinline__ void next() { q += dq; r += dr; if (r >= d) { r -= d; ++q; } }
 };
 
+// Plane loads of the depthwise kernels: a bounds-checked buffer load per element (an offset of kOOB reads 0: the zero border, the
+// tail of a loop, a missing plane) — no branch around the load, so that the U loads of an unrolled chunk are ALL in flight before
+// the first one is used.  (Round 4: the loops used to run `global_load_dword; s_waitcnt vmcnt(0)` per iteration — one load in flight
+// per thread, ~5 KB per CU where ~40 KB are needed to cover HBM latency: the strip kernels ran at 3.1-3.3 TB/s; batched: fused
+// backward 198.6 -> 140.6 us at 56x56 (4.4 TB/s), 93.0 -> 63.7 us at 28x28, forward 58.5 -> 52.5 / 31.5 -> 29.1 us.  The
+// one-wavefront-per-plane kernels below keep their simple loops: with seven descriptors and 28 loads per lane up front they got
+// SLOWER, 44.1 -> 53.2 us at 14x14 — many small waves already keep enough loads in flight there.)
+__device__ __forceinline__ float ldb(rsrc_t r, int off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+}
+constexpr int kDwU = 4;      // elements per thread and chunk
+
 // ---- depthwise 3x3 conv + bias + SiLU (MedMamba.py:153-162, 295), writing the scan's two input orders --------
 // x: planes (b, d) of H*W floats, batch stride x_sb, channel stride H*W.  out u2: (batch, 2, D, L):
 // u2[b,0,d,h*W+w] = u2[b,1,d,w*H+h] = silu(conv(x)[b,d,h,w] + bias[d]).
@@ -163,11 +175,21 @@ __global__ __launch_bounds__(256) void dwconv_silu_cross_fwd_kernel(const float*
   float* sx = lds;                         // (sh+2) x (W+2): rows r0-1 .. r0+sh, zero outside the plane
   float* so = lds + (SH + 2) * WP;         // sh x (W+1)
   const float* xp = x + (int64_t)b * x_sb + (int64_t)d * x_sd;
+  const rsrc_t rx = make_rsrc(xp, (int64_t)H * W * 4);
   {
     DivMod dm(tid, nt, WP);
-    for (int i = tid; i < (sh + 2) * WP; i += nt, dm.next()) {
-      const int hh = r0 + dm.q - 1, ww = dm.r - 1;
-      sx[i] = (hh >= 0 && hh < H && ww >= 0 && ww < W) ? xp[hh * W + ww] : 0.f;
+    const int N = (sh + 2) * WP;
+    for (int i = tid; i < N; i += kDwU * nt) {
+      float v[kDwU];
+#pragma unroll
+      for (int u = 0; u < kDwU; ++u) {
+        const int hh = r0 + dm.q - 1, ww = dm.r - 1;
+        v[u] = ldb(rx, (i + u * nt < N && hh >= 0 && hh < H && ww >= 0 && ww < W) ? (hh * W + ww) * 4 : kOOB);
+        dm.next();
+      }
+#pragma unroll
+      for (int u = 0; u < kDwU; ++u)
+        if (i + u * nt < N) sx[i + u * nt] = v[u];
     }
   }
   float k[9];
@@ -226,18 +248,46 @@ __global__ __launch_bounds__(256) void dwconv_silu_cross_bwd_kernel(const float*
   const float* g1 = du2 + b * g_sb + (D + d) * g_sd;
   const float* e0 = du4 ? du4 + b * e_sb + d * e_sd : nullptr;          // direction 0; direction k at e0 + k*D*e_sd
   const int64_t eD = (int64_t)D * e_sd;
+  const int64_t pbytes = (int64_t)H * W * 4;
+  const rsrc_t rx = make_rsrc(xp, pbytes), rg0 = make_rsrc(g0, pbytes), rg1 = make_rsrc(g1, pbytes);
+  // the scan's four per-direction gradients (empty descriptors without du4: every load reads 0)
+  const rsrc_t re0 = make_rsrc(e0, e0 ? pbytes : 0), re1 = make_rsrc(e0 ? e0 + eD : nullptr, e0 ? pbytes : 0),
+               re2 = make_rsrc(e0 ? e0 + 2 * eD : nullptr, e0 ? pbytes : 0), re3 = make_rsrc(e0 ? e0 + 3 * eD : nullptr, e0 ? pbytes : 0);
   {
     DivMod dm(tid, nt, WP);
-    for (int i = tid; i < (sh + 4) * WP; i += nt, dm.next()) {
-      const int hh = r0 + dm.q - 2, ww = dm.r - 1;
-      sx[i] = (hh >= 0 && hh < H && ww >= 0 && ww < W) ? xp[hh * W + ww] : 0.f;
+    const int N = (sh + 4) * WP;
+    for (int i = tid; i < N; i += kDwU * nt) {
+      float v[kDwU];
+#pragma unroll
+      for (int u = 0; u < kDwU; ++u) {
+        const int hh = r0 + dm.q - 2, ww = dm.r - 1;
+        v[u] = ldb(rx, (i + u * nt < N && hh >= 0 && hh < H && ww >= 0 && ww < W) ? (hh * W + ww) * 4 : kOOB);
+        dm.next();
+      }
+#pragma unroll
+      for (int u = 0; u < kDwU; ++u)
+        if (i + u * nt < N) sx[i + u * nt] = v[u];
     }
   }
   for (int i = tid; i < (sh + 2) * WP; i += nt) sd[i] = 0.f;
-  DivMod dg(tid, nt, gh);
-  for (int i = tid; i < gh * W; i += nt, dg.next()) {  // i = w*gh + hg (lanes along h)
-    const int w = dg.q, hg = dg.r, h = ge0 + hg;
-    st[(h - (r0 - 1)) * (W + 1) + w] = g1[w * H + h] + (e0 ? e0[2 * eD + w * H + h] + e0[3 * eD + w * H + h] : 0.f);
+  {
+    DivMod dg(tid, nt, gh);
+    const int N = gh * W;
+    for (int i = tid; i < N; i += kDwU * nt) {   // i = w*gh + hg (lanes along h)
+      float v[kDwU][3];
+      int at[kDwU];
+#pragma unroll
+      for (int u = 0; u < kDwU; ++u) {
+        const int w = dg.q, h = ge0 + dg.r;
+        const int off = i + u * nt < N ? (w * H + h) * 4 : kOOB;
+        v[u][0] = ldb(rg1, off); v[u][1] = ldb(re2, off); v[u][2] = ldb(re3, off);
+        at[u] = (h - (r0 - 1)) * (W + 1) + w;
+        dg.next();
+      }
+#pragma unroll
+      for (int u = 0; u < kDwU; ++u)
+        if (i + u * nt < N) st[at[u]] = v[u][0] + (v[u][1] + v[u][2]);
+    }
   }
   float k[9];
 #pragma unroll
@@ -248,8 +298,23 @@ __global__ __launch_bounds__(256) void dwconv_silu_cross_bwd_kernel(const float*
 #pragma unroll
   for (int i = 0; i < 10; ++i) acc[i] = 0.f;
   DivMod dc(tid, nt, W);
-  for (int i = tid; i < gh * W; i += nt, dc.next()) {
-    const int hg = dc.q, w = dc.r, h = ge0 + hg;
+  const int NG = gh * W;
+  for (int i0 = tid; i0 < NG; i0 += kDwU * nt) {
+    // the chunk's row-major gradients first (3 loads per element, all in flight), then the arithmetic
+    float gin[kDwU];
+    int hs[kDwU], wsv[kDwU];
+#pragma unroll
+    for (int u = 0; u < kDwU; ++u) {
+      const int h = ge0 + dc.q, w = dc.r;
+      const int off = i0 + u * nt < NG ? (h * W + w) * 4 : kOOB;
+      gin[u] = ldb(rg0, off) + (ldb(re0, off) + ldb(re1, off));
+      hs[u] = h; wsv[u] = w;
+      dc.next();
+    }
+#pragma unroll
+    for (int u = 0; u < kDwU; ++u) {
+    if (i0 + u * nt < NG) {
+    const int h = hs[u], w = wsv[u];
     const int hl = h - (r0 - 1);                        // row inside sd / st (0 .. sh+1)
     const float* c = sx + hl * WP + w;                 // sx row of h-1 is (h-1) - (r0-2) = hl
     float p = bs;
@@ -258,8 +323,7 @@ __global__ __launch_bounds__(256) void dwconv_silu_cross_bwd_kernel(const float*
 #pragma unroll
       for (int kw = 0; kw < 3; ++kw) p = fmaf(c[kh * WP + kw], k[kh * 3 + kw], p);
     const float sg = sigmoid_f(p);
-    const float ge = e0 ? e0[h * W + w] + e0[eD + h * W + w] : 0.f;
-    const float dp = (g0[h * W + w] + ge + st[hl * (W + 1) + w]) * (sg * (1.f + p * (1.f - sg)));   // silu'(p) = s (1 + p (1 - s))
+    const float dp = (gin[u] + st[hl * (W + 1) + w]) * (sg * (1.f + p * (1.f - sg)));   // silu'(p) = s (1 + p (1 - s))
     sd[hl * WP + (w + 1)] = dp;
     if (h >= r0 && h < r0 + sh) {                       // parameter gradients: every row is owned by exactly one strip
       acc[9] += dp;
@@ -267,6 +331,8 @@ __global__ __launch_bounds__(256) void dwconv_silu_cross_bwd_kernel(const float*
       for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) acc[kh * 3 + kw] = fmaf(dp, c[kh * WP + kw], acc[kh * 3 + kw]);
+    }
+    }
     }
   }
   __syncthreads();
