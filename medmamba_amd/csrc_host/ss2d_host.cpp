@@ -102,6 +102,20 @@ inline void gemm_out(Tensor& out, const Tensor& a, const Tensor& b, void* stream
   }
 }
 
+// t.sum(0) through mm_sum_lead for dense fp32 tensors (ops.sum_lead: the same call, the same conditions — both routes give the
+// same bits); `out` (optional) must be dense with the shape of t[0]
+inline Tensor sum_lead(const Tensor& t, void* stream, const Tensor& out_ = Tensor()) {
+  const int64_t n = t.dim() >= 1 ? t.size(0) : 0;
+  if (t.dim() >= 2 && n >= 2 && t.is_contiguous() && t.numel() > 0 && (!out_.defined() || (out_.is_contiguous() && out_.numel() * n == t.numel()))) {
+    Tensor out = out_.defined() ? out_ : at::empty(t.sizes().slice(1), t.options());
+    const int64_t ninner = t.numel() / n;
+    check(mm_sum_lead(fp(t), fpm(out), (int)n, ninner, ninner, stream), "mm_sum_lead");
+    return out;
+  }
+  if (out_.defined()) { Tensor o = out_; at::sum_out(o, t, DIM0); return o; }
+  return t.sum(0);
+}
+
 inline Tensor gemm_new(const Tensor& a, const Tensor& b, void* stream) {      // batched product into a fresh (B, m, n) tensor
   Tensor out = at::empty({a.dim() == 3 ? a.size(0) : b.size(0), a.size(-2), b.size(-1)}, a.options());
   gemm_out(out, a, b, stream);
@@ -277,7 +291,7 @@ std::vector<Tensor> ss2d_bwd(const Tensor& dout_, const Tensor& x, const Tensor&
     const Tensor g = rows(dout_);
     dy = at::empty({Bsz, D, L}, o);
     gemm_out(dy, out_w.t(), g, stream);
-    d_out_w = gemm_new(g, rows(y).transpose(1, 2), stream).sum(0);
+    d_out_w = sum_lead(gemm_new(g, rows(y).transpose(1, 2), stream), stream);
   }
   // out_norm + gate backward, its plane transpose for the column-major directions
   Tensor dout2 = planes(Bsz, 2 * D, L, o, cm);            // channel block 0: dm, block 1: its plane transpose
@@ -354,14 +368,14 @@ std::vector<Tensor> ss2d_bwd(const Tensor& dout_, const Tensor& x, const Tensor&
     const Tensor dd = ddelta.view({Bsz, 4, D, L});
     const Tensor xr = x_dbl.narrow(2, 0, R);
     Tensor dWdt = ds.Wdt;
-    at::sum_out(dWdt, at::matmul(dd, xr.transpose(-1, -2)), DIM0);                          // (4, D, R)
+    sum_lead(at::matmul(dd, xr.transpose(-1, -2)), stream, dWdt);                           // (4, D, R)
     dx_dbl.narrow(2, 0, R).copy_(at::matmul(s.Wdt.transpose(-1, -2).unsqueeze(0), dd));    // dt rows of d(x_dbl)
     const Tensor Wx2 = s.Wx.view({2, 2 * C, D});
     const Tensor dxd2 = dx_dbl.view({Bsz, 2, 2 * C, L});
     const Tensor WxT = Wx2.transpose(1, 2).unsqueeze(0).expand({Bsz, -1, -1, -1}).reshape({Bsz * 2, D, 2 * C});
     du2 = at::bmm(WxT, dxd2.reshape({Bsz * 2, 2 * C, L}));                                 // Wx^T d(x_dbl); pairs added later
     Tensor dWx = ds.Wx.view({2, 2 * C, D});
-    at::sum_out(dWx, at::matmul(dxd2, u2.view({Bsz, 2, D, L}).transpose(-1, -2)), DIM0);
+    sum_lead(at::matmul(dxd2, u2.view({Bsz, 2, D, L}).transpose(-1, -2)), stream, dWx);
     du2 = du2.view({Bsz, 2 * D, L});
   }
   // d(u2) = projection part + the scan's two direction pairs, summed inside the depthwise conv's backward kernel
@@ -380,7 +394,7 @@ std::vector<Tensor> ss2d_bwd(const Tensor& dout_, const Tensor& x, const Tensor&
         "mm_ss2d_pack_bwd");
   const Seg gs = segments(G.narrow(0, 0, npk), D, C, R, N);
   if (!pack_fold) {                                     // A/B switch (MM_PACK_FOLD=0): the reductions as separate ATen launches
-    ln_out = ws.sum(0);
+    ln_out = sum_lead(ws, stream);
     const Tensor sc = wsc.view({Bsz, D, -1, 10}).sum(at::IntArrayRef({0, 2}));
     dw_out = at::cat({sc.narrow(1, 0, 9).reshape({-1}), sc.select(1, 9)});
   }
@@ -397,7 +411,7 @@ std::vector<Tensor> ss2d_bwd(const Tensor& dout_, const Tensor& x, const Tensor&
   } else {
     dx = at::empty({Bsz, L, dm}, o);
     gemm_out(dx, dxz.transpose(1, 2), in_w, stream);
-    at::sum_out(d_in_w, gemm_new(dxz, x, stream), DIM0);
+    sum_lead(gemm_new(dxz, x, stream), stream, d_in_w);
   }
   return {dx, d_in_w, dcw, dcb, gs.Wx, gs.Wdt, gs.bias.view({4, D}), gs.A, gs.Dp, ln_out.narrow(0, 0, D), ln_out.narrow(0, D, D), d_out_w};
 }
@@ -425,7 +439,7 @@ inline Tensor bias_grad(const Tensor& dy, void* stream) {      // ops._bias_grad
   const int split = mm_channel_sum_nchw_split((int)B, (int)C);
   Tensor out = at::empty({split, C}, dy.options());
   check(mm_channel_sum_nchw(fp(dy), fpm(out), (int)B, (int)C, (int)HW, stream), "mm_channel_sum_nchw");
-  return split == 1 ? out.select(0, 0) : out.sum(0);
+  return split == 1 ? out.select(0, 0) : sum_lead(out, stream);
 }
 
 // returns {dx, dgamma, dbeta, d(pre_bias) or undefined}
@@ -468,7 +482,7 @@ std::pair<Tensor, Tensor> conv3x3_bwd(const Tensor& dy, const Tensor& x, const T
   check(mm_im2col3x3(fp(x), fpm(cols), (int)B, (int)C, (int)x.size(2), (int)x.size(3), (int)gs, stream), "mm_im2col3x3");
   const Tensor dyg = gs == 1 ? dy.reshape({B, K, HW})
                              : dy.reshape({B / gs, gs, K, HW}).transpose(1, 2).reshape({B / gs, K, gs * HW});   // one copy
-  Tensor dw = at::bmm(dyg, cols.transpose(1, 2)).sum(0).view(w.sizes());
+  Tensor dw = sum_lead(at::bmm(dyg, cols.transpose(1, 2)), stream).view(w.sizes());
   return {std::get<0>(r), dw};
 }
 
@@ -503,7 +517,7 @@ std::vector<Tensor> conv_branch_bwd(const Tensor& dout, const Tensor& x, const T
   const Tensor w3v = w3.view({K, C}), y3v = y3.view({B, C, H * W});
   Tensor dy3 = at::empty({B, C, H * W}, x.options());
   gemm_out(dy3, w3v.t(), dy, stream);
-  Tensor dw3 = gemm_new(dy, y3v.transpose(1, 2), stream).sum(0).view(w3.sizes());
+  Tensor dw3 = sum_lead(gemm_new(dy, y3v.transpose(1, 2), stream), stream).view(w3.sizes());
   auto r3 = bn_bwd(dy3.view({B, C, H, W}), c2, g3, b3, s3, true, true, stream);
   auto cbw2 = conv3x3_bwd(r3[0], y2, w2, stream);
   auto r2 = bn_bwd(cbw2.first, c1, g2, b2, s2, true, true, stream);

@@ -28,6 +28,23 @@ def _gemm(a, b, out=None, batch=None):
     return out
 
 
+def sum_lead(t, out=None):
+    """t.sum(0) — the sum over the batch behind a batched weight-gradient GEMM, over per-workgroup partial rows, ... — through
+    mm_sum_lead for dense fp32 HIP tensors (one small launch with a fixed summation order instead of ATen's generic 10-us
+    reduction; csrc_host sum_lead is the same call, so both launch routes give the same bits); anything else through torch."""
+    n = t.shape[0] if t.dim() >= 1 else 0
+    if (t.is_cuda and t.dtype == torch.float32 and t.dim() >= 2 and n >= 2 and t.is_contiguous() and t.numel() > 0
+            and (out is None or (out.is_contiguous() and out.dtype == torch.float32 and out.numel() * n == t.numel()))):
+        if out is None:
+            out = torch.empty(t.shape[1:], device=t.device, dtype=torch.float32)
+        ninner = t.numel() // n
+        with _lib.device_guard(t.device):
+            rc = _lib.lib().mm_sum_lead(t.data_ptr(), out.data_ptr(), n, ninner, ninner, _stream())
+        _lib.check(rc, "mm_sum_lead")
+        return out
+    return t.sum(0) if out is None else torch.sum(t, 0, out=out)
+
+
 def _wants_grad(*ts):
     """Does anything downstream differentiate this call?  Inside Function.forward grad mode is always off and
     ctx.needs_input_grad ignores torch.no_grad(), so the wrappers decide here and pass a plain flag: under no_grad (the usual
@@ -203,7 +220,7 @@ class InProjFn(torch.autograd.Function):
                 _gemm(g2, x2, out=dw)
             else:
                 dx = _gemm(g.transpose(1, 2), weight)
-                torch.sum(_gemm(g, x), dim=0, out=dw)
+                sum_lead(_gemm(g, x), out=dw)
         elif ctx.cm:
             gx, gz, x2 = _cm2d(dx_cf), _cm2d(dz_cf), x.view(Bsz * L, dm)                         # (D, B*L) each
             dx = torch.mm(gx.t(), w0)
@@ -215,8 +232,8 @@ class InProjFn(torch.autograd.Function):
             # d x (B, L, dm) = dx_cf^T @ W[:D] + dz_cf^T @ W[D:]
             dx = torch.bmm(dx_cf.transpose(1, 2), w0.unsqueeze(0).expand(Bsz, -1, -1))
             dx.baddbmm_(dz_cf.transpose(1, 2), w1.unsqueeze(0).expand(Bsz, -1, -1))
-            torch.sum(torch.bmm(dx_cf, x), dim=0, out=dw[:D])
-            torch.sum(torch.bmm(dz_cf, x), dim=0, out=dw[D:])
+            sum_lead(torch.bmm(dx_cf, x), out=dw[:D])
+            sum_lead(torch.bmm(dz_cf, x), out=dw[D:])
         db = None
         if ctx.has_bias:
             db = torch.cat([dx_cf.sum(dim=(0, 2)), dz_cf.sum(dim=(0, 2))])
@@ -259,7 +276,7 @@ class OutProjFn(torch.autograd.Function):
             if ctx.needs_input_grad[0]:
                 dy = _gemm(weight.t(), g)
             if ctx.needs_input_grad[1]:
-                dw = _gemm(g, _rows(y_cf).transpose(1, 2)).sum(0)
+                dw = sum_lead(_gemm(g, _rows(y_cf).transpose(1, 2)))
         return dy, dw
 
 
@@ -477,7 +494,7 @@ class SS2DCoreFn(torch.autograd.Function):
         else:
             dd = ddelta.view(Bsz, 4, D, L)
             xr = x_dbl[:, :, :R]
-            torch.sum(torch.matmul(dd, xr.transpose(-1, -2)), 0, out=dWdt)                       # (4, D, R)
+            sum_lead(torch.matmul(dd, xr.transpose(-1, -2)), out=dWdt)                           # (4, D, R)
             dx_dbl[:, :, :R] = torch.matmul(Wdt.transpose(-1, -2).unsqueeze(0), dd)               # dt rows of d(x_dbl)
             Wx2 = Wx.view(2, 2 * C, D)
             dxd2 = dx_dbl.view(Bsz, 2, 2 * C, L)
@@ -488,7 +505,7 @@ class SS2DCoreFn(torch.autograd.Function):
                 d4 = du4.view(Bsz, 2, 2, D, L)
                 du2 = (d4[:, :, 0] + d4[:, :, 1]).view(Bsz * 2, D, L)                             # the two directions of a pair
                 du2.baddbmm_(WxT, dxd2.reshape(Bsz * 2, 2 * C, L))                               # + Wx^T d(x_dbl)
-            torch.sum(torch.matmul(dxd2, u2.view(Bsz, 2, D, L).transpose(-1, -2)), 0, out=dWx.view(2, 2 * C, D))
+            sum_lead(torch.matmul(dxd2, u2.view(Bsz, 2, D, L).transpose(-1, -2)), out=dWx.view(2, 2 * C, D))
             du2 = du2.view(Bsz, 2 * D, L)
         dcw = dcb = wsc = None
         strips = 0
@@ -517,7 +534,7 @@ class SS2DCoreFn(torch.autograd.Function):
         _lib.check(rc, "mm_ss2d_pack_bwd")
         gWx, gWdt, gA, gD, gb = SS2DCoreFn._segments(G[:npk], D, C, R, N)
         if not fold:                                  # A/B switch (MM_PACK_FOLD=0): the reductions as separate ATen launches
-            ln_out = ws.sum(0)
+            ln_out = sum_lead(ws)
             if wsc is not None:
                 sc = wsc.view(Bsz, D, -1, 10).sum((0, 2))
                 dw_out = torch.cat([sc[:, :9].reshape(-1), sc[:, 9]])
@@ -633,7 +650,7 @@ def channel_sum_nchw(x):
     with _lib.device_guard(x.device):
         rc = lib.mm_channel_sum_nchw(x.data_ptr(), out.data_ptr(), B, C, HW, _stream())
     _lib.check(rc, "mm_channel_sum_nchw")
-    return out[0] if split == 1 else out.sum(0)        # rows of per-batch-part sums, added in a fixed order (no atomics)
+    return out[0] if split == 1 else sum_lead(out)     # rows of per-batch-part sums, added in a fixed order (no atomics)
 
 
 def _bias_grad(dy):
@@ -678,7 +695,7 @@ class ConvBiasFn(torch.autograd.Function):
                 _lib.check(_lib.lib().mm_im2col3x3(x.data_ptr(), cols.data_ptr(), B, C, x.shape[2], x.shape[3], gs, _stream()),
                            "mm_im2col3x3")
             dyg = dy.reshape(B, K, HW) if gs == 1 else dy.reshape(B // gs, gs, K, HW).transpose(1, 2).reshape(B // gs, K, gs * HW)
-            dw = torch.bmm(dyg, cols.transpose(1, 2)).sum(0).view(w.shape)
+            dw = sum_lead(torch.bmm(dyg, cols.transpose(1, 2))).view(w.shape)
         else:
             dx, dw, _ = torch.ops.aten.convolution_backward(dy, x, w, None, stride, padding, dilation, False, [0, 0], 1,
                                                             [ctx.needs_input_grad[0], ctx.needs_input_grad[1], False])
@@ -721,7 +738,7 @@ class PointwiseConvFn(torch.autograd.Function):
         B, C, H, W, has_bias, wshape = ctx.shape
         dy3 = dy.contiguous().view(B, -1, H * W)
         dx = _gemm(w.t(), dy3).view(B, C, H, W) if ctx.needs_input_grad[0] else None
-        dw = _gemm(dy3, x3.transpose(1, 2)).sum(0).view(wshape) if ctx.needs_input_grad[1] else None
+        dw = sum_lead(_gemm(dy3, x3.transpose(1, 2))).view(wshape) if ctx.needs_input_grad[1] else None
         db = _bias_grad(dy3) if (has_bias and ctx.needs_input_grad[2]) else None
         return dx, dw, db
 
@@ -766,7 +783,7 @@ class BlockSplitFn(torch.autograd.Function):
                                         inp.data_ptr(), gamma.data_ptr(), mu.data_ptr(), rstd.data_ptr(), dinp.data_ptr(),
                                         ws.data_ptr(), B, P, C2, _stream())
         _lib.check(rc, "mm_block_split_bwd")
-        s = ws.sum(0)
+        s = sum_lead(ws)
         return dinp, s[:C2], s[C2:], None
 
 
@@ -832,7 +849,7 @@ class PatchMergeLNFn(torch.autograd.Function):
             rc = lib.mm_patch_merge_ln_bwd(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(),
                                            dinp.data_ptr(), ws.data_ptr(), B, H, W, C, _stream())
         _lib.check(rc, "mm_patch_merge_ln_bwd")
-        s = ws.sum(0)
+        s = sum_lead(ws)
         return dinp, s[0], s[1], None
 
 
@@ -876,7 +893,7 @@ class NchwLNRowsFn(torch.autograd.Function):
             rc = lib.mm_nchw_ln_rows_bwd(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(),
                                          dx.data_ptr(), ws.data_ptr(), B, C, H * W, _stream())
         _lib.check(rc, "mm_nchw_ln_rows_bwd")
-        s = ws.sum(0)
+        s = sum_lead(ws)
         return dx, s[0], s[1], None
 
 

@@ -638,3 +638,22 @@ def test_im2col3x3_is_unfold(shape):
             want = ref.view(B // gs, gs, 9 * C, H * W).transpose(1, 2).reshape(B // gs, 9 * C, gs * H * W)
             assert torch.equal(grouped, want), gs
     assert _lib.lib().mm_im2col3x3(x.data_ptr(), cols.data_ptr(), B, C, H, W, 0, None) == -2
+
+
+@pytest.mark.parametrize("shape", [(64, 4, 35, 96), (2, 7), (3, 1), (64, 768, 384), (5, 13), (17, 2, 48, 48), (130, 10), (1, 8)])
+def test_sum_lead_matches_torch_sum_and_is_reproducible(shape):
+    """mm_sum_lead (ops.sum_lead / csrc_host sum_lead): t.sum(0) of dense fp32 tensors — the batch sums behind the batched
+    weight-gradient GEMMs and the partial rows — vector and scalar form, into a fresh tensor and into a given one."""
+    from medmamba_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(sum(shape))
+    t = torch.randn(*shape, device=DEV, generator=g)
+    want = t.double().sum(0)
+    got = ops.sum_lead(t)
+    assert got.shape == want.shape
+    assert float((got.double() - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max()))
+    out = torch.full(shape[1:], float("nan"), device=DEV)
+    assert ops.sum_lead(t, out=out) is out and torch.equal(out, got)          # same bits on every call: fixed summation order
+    # a view that is not dense takes torch's path and still gives the sum
+    if len(shape) >= 2 and shape[-1] > 1:
+        tv = t[..., ::2]
+        assert torch.allclose(ops.sum_lead(tv), tv.sum(0), rtol=1e-5, atol=1e-5)
