@@ -28,6 +28,34 @@ def _gemm(a, b, out=None, batch=None):
     return out
 
 
+class _BranchTimer:
+    """Diagnostic (tools/branch_balance.py; off unless enabled): device events around the forward / backward of a block's two
+    branches, each on the stream the branch runs on — which branch of which block the other one waits for, WITHOUT a profiler
+    slowing the host down (under rocprofv3 the host falls behind the GPU and the side stream starts late, which the unprofiled
+    step does not do)."""
+
+    def __init__(self):
+        self.enabled = False
+        self.records = []          # (tag, start_event, end_event)
+
+    def start(self):
+        if not self.enabled:
+            return None
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        return ev
+
+    def stop(self, tag, start):
+        if start is None:
+            return
+        end = torch.cuda.Event(enable_timing=True)
+        end.record()
+        self.records.append((tag, start, end))
+
+
+BRANCH_TIMER = _BranchTimer()
+
+
 def sum_lead(t, out=None):
     """t.sum(0) — the sum over the batch behind a batched weight-gradient GEMM, over per-workgroup partial rows, ... — through
     mm_sum_lead for dense fp32 HIP tensors (one small launch with a fixed summation order instead of ATen's generic 10-us
@@ -560,9 +588,11 @@ class SS2DBranchFn(torch.autograd.Function):
         need_grad = bool(need_grad) and any(ctx.needs_input_grad)
         x = x.contiguous()
         with _lib.device_guard(x.device):
+            bt = BRANCH_TIMER.start()
             ev0, ev1 = KERNEL_TIMER.pair("scan_fwd", scan_bytes_fwd(Bsz, 4 * D, L, N, 4), Bsz * 4 * D * L * N)
             res = _host.module().ss2d_fwd(x, in_w, conv_w, conv_b, x_proj_w, dt_w, dt_b, A_logs, Ds, ln_w, ln_b, out_w, H, W, float(eps),
                                           cm, need_grad, _FWD_VARIANT, _stream(), ev0, ev1, prescan_event, _FUSE_DT)
+            BRANCH_TIMER.stop("ss2d_fwd", bt)
         if need_grad:
             ctx.save_for_backward(x, in_w, conv_w, conv_b, ln_w, ln_b, out_w, *res[1:])
             ctx.dims = (H, W, cm)
@@ -577,9 +607,11 @@ class SS2DBranchFn(torch.autograd.Function):
         Bsz, L, _ = x.shape
         D = in_w.shape[0] // 2
         with _lib.device_guard(x.device):
+            bt = BRANCH_TIMER.start()
             ev0, ev1 = KERNEL_TIMER.pair("scan_bwd", scan_bytes_bwd(Bsz, 4 * D, L, 16, 4), Bsz * 4 * D * L * 16)
             g = _host.module().ss2d_bwd(dout, x, in_w, conv_w, conv_b, ln_w, ln_b, out_w, xz, u2, x_dbl, delta, P, x_chk, m, mu, rstd, y,
                                         H, W, cm, _PACK_FOLD, _BWD_VARIANT, _stream(), ev0, ev1)
+            BRANCH_TIMER.stop("ss2d_bwd", bt)
         dx, d_in, dcw, dcb, gWx, gWdt, gb, gA, gD, dlw, dlb, d_out = g
         return dx, d_in, dcw, dcb, gWx, gWdt, gb, gA, gD, dlw, dlb, d_out, None, None, None, None, None
 
@@ -1025,8 +1057,10 @@ class ConvBranchFn(torch.autograd.Function):
     def forward(ctx, x, g1, b1, w1, cb1, g2, b2, w2, cb2, g3, b3, w3, buffers, eps_mom):
         from . import _host
         with _lib.device_guard(x.device):
+            bt = BRANCH_TIMER.start()
             res = _host.module().conv_branch_fwd(x, [g1, b1, buffers[0], buffers[1]], w1, cb1, [g2, b2, buffers[2], buffers[3]], w2, cb2,
                                                  [g3, b3, buffers[4], buffers[5]], w3, eps_mom, _stream())
+            BRANCH_TIMER.stop("conv_fwd", bt)
         ctx.save_for_backward(x, g1, b1, w1, g2, b2, w2, g3, b3, w3, *res[1:])
         return res[0]
 
@@ -1035,7 +1069,9 @@ class ConvBranchFn(torch.autograd.Function):
         from . import _host
         t = ctx.saved_tensors
         with _lib.device_guard(dout.device):
+            bt = BRANCH_TIMER.start()
             g = _host.module().conv_branch_bwd(dout, *t, _stream())
+            BRANCH_TIMER.stop("conv_bwd", bt)
         return (*g, None, None)
 
 
