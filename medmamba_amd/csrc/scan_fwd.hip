@@ -629,8 +629,15 @@ __global__ __launch_bounds__(1024) void scan_fwd_wg_kernel(const FwdParams p) {
 template <bool SP>
 int launch_wg(const FwdParams& p, int ncw, int nwv, hipStream_t stream) {
   const size_t lds = sizeof(float) * (size_t)(kWgBC + nwv * kWgWave);
-  if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute((const void*)scan_fwd_wg_kernel<SP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  // more than 64 KB of dynamic LDS must be allowed once per kernel and device (idempotent: racing threads set the same value);
+  // the largest request is that of 16 waves, so allow it the first time any launch needs the attribute
+  static bool allowed[64] = {};
+  int dev = 0;
+  if (lds > 64 * 1024 && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && !allowed[dev]) {
+    (void)hipFuncSetAttribute((const void*)scan_fwd_wg_kernel<SP>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)(sizeof(float) * (size_t)(kWgBC + 16 * kWgWave)));
+    allowed[dev] = true;
+  }
   FwdParams q = p;
   q.ntiles = (p.L + kWgT - 1) / kWgT;
   q.wpg = ncw;
