@@ -360,8 +360,8 @@ int mm_ss2d_pack_parts_size(int D, int C, int R, int N);
 int mm_channel_sum_nchw_split(int batch, int C);
 int mm_channel_sum_nchw(const float* x, float* out, int batch, int C, int HW, void* stream);
 
-/* dst[i] = sum_{j < nlead} src[j * lead_stride + i] for i < ninner (fp32, fixed summation order: 4 interleaved parts of the lead
- * dimension, each summed in order, joined as (p0 + p1) + (p2 + p3)) — the sum over the batch behind the batched weight-gradient
+/* dst[i] = sum_{j < nlead} src[j * lead_stride + i] for i < ninner (fp32, fixed summation order: 4 ... 32 interleaved parts of
+ * the lead dimension — by the width of the tensor —, each summed in order, then joined in order) — the sum over the batch behind the batched weight-gradient
  * GEMMs of MedMamba.py:259, 262, 292, 302 in batch-major storage and behind per-workgroup partial rows (since ABI 21). */
 int mm_sum_lead(const float* src, float* dst, int nlead, int64_t ninner, int64_t lead_stride, void* stream);
 

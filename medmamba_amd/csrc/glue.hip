@@ -153,6 +153,9 @@ struct DivMod {
 __device__ __forceinline__ float ldb(rsrc_t r, int off) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
 }
+__device__ __forceinline__ void stb(rsrc_t r, int off, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, off, 0, 0);
+}
 constexpr int kDwU = 4;      // elements per thread and chunk
 
 // ---- depthwise 3x3 conv + bias + SiLU (MedMamba.py:153-162, 295), writing the scan's two input orders --------
@@ -673,6 +676,16 @@ __device__ __forceinline__ float low_sum(float v) {
   return v;
 }
 
+// Channel rows of the LayerNorm + gate kernels through buffer descriptors (Round 4): the CPL loads of a lane used to sit behind
+// `in ? p[d * sd] : 0` — a branch per load and `s_waitcnt vmcnt(0)` before the next one, 3-4 loads in flight per lane where the
+// latency of HBM wants dozens (ln_gate_bwdc<32,8,24> alone: 1.7 TB/s).  Here: one descriptor per step k that starts at the first
+// channel row of the wave's step (a wave-uniform 64-bit base: no 32-bit limit on D * channel stride), a per-lane byte offset
+// (row inside the step, position) that is kOOB for lanes without work — no control flow, every load issued up front.
+// (the host checks (rows - 1) * sd + L < 2^29 elements: mm_ln_gate_fwd / _bwd)
+__device__ __forceinline__ rsrc_t rows_rsrc(const float* base, int d0, int64_t sd, int rows, int L) {
+  return make_rsrc(base + (int64_t)d0 * sd, ((int64_t)(rows - 1) * sd + L) * 4);
+}
+
 template <int PW>
 __device__ __forceinline__ float pos_sum(float v) {   // sum over the 64/PW lanes that share a position
 #pragma unroll
@@ -808,15 +821,18 @@ __global__ __launch_bounds__(256) void ln_gate_fwd1_kernel(const float* __restri
   const int p = (pb * 4 + wv) * PW + (lane % PW);
   const int ck = lane / PW;
   const bool ok = p < L;
-  const float* mp = m + (int64_t)b * m_sb + p;
-  const float* zp = z + (int64_t)b * z_sb + p;
-  float mv[CPL], s1 = 0.f;
+  const float* mb = m + (int64_t)b * m_sb;
+  const float* zb = z + (int64_t)b * z_sb;
+  const int om = ok ? (ck * (int)m_sd + p) * 4 : kOOB, oz = ok ? (ck * (int)z_sd + p) * 4 : kOOB;
+  float mv[CPL], zv[CPL], s1 = 0.f;
 #pragma unroll
   for (int k = 0; k < CPL; ++k) {
-    const int d = ck + k * TPP;
-    mv[k] = (ok && d < D) ? mp[d * m_sd] : 0.f;
-    s1 += mv[k];
+    const bool in = ck + k * TPP < D;
+    mv[k] = ldb(rows_rsrc(mb, k * TPP, m_sd, TPP, L), in ? om : kOOB);
+    zv[k] = ldb(rows_rsrc(zb, k * TPP, z_sd, TPP, L), in ? oz : kOOB);
   }
+#pragma unroll
+  for (int k = 0; k < CPL; ++k) s1 += mv[k];
   const float mu = pos_sum<PW>(s1) / D;
   float s2 = 0.f;
 #pragma unroll
@@ -825,20 +841,19 @@ __global__ __launch_bounds__(256) void ln_gate_fwd1_kernel(const float* __restri
     s2 = fmaf(dv, dv, s2);
   }
   const float rstd = __builtin_amdgcn_rsqf(pos_sum<PW>(s2) / D + eps);
-  if (!ok) return;
-  if (ck == 0) {
+  if (ok && ck == 0) {
     mu_out[(int64_t)b * L + p] = mu;
     rstd_out[(int64_t)b * L + p] = rstd;
   }
-  float* yp = y + (int64_t)b * y_sb + p;
+  float* yb = y + (int64_t)b * y_sb;
+  const int oy = ok ? (ck * (int)y_sd + p) * 4 : kOOB;
+  const rsrc_t rgam = make_rsrc(gamma, (int64_t)D * 4), rbet = make_rsrc(beta, (int64_t)D * 4);
 #pragma unroll
   for (int k = 0; k < CPL; ++k) {
-    const int d = ck + k * TPP;
-    if (d < D) {
-      const float n = (mv[k] - mu) * rstd * gamma[d] + beta[d];
-      const float zz = zp[d * z_sd];
-      yp[d * y_sd] = n * (zz * sigmoid_f(zz));
-    }
+    const int d = ck + k * TPP;                                     // d >= D: gamma / beta read 0, the store is dropped
+    const float n = (mv[k] - mu) * rstd * ldb(rgam, d * 4) + ldb(rbet, d * 4);
+    const float zz = zv[k];
+    stb(rows_rsrc(yb, k * TPP, y_sd, TPP, L), d < D ? oy : kOOB, n * (zz * sigmoid_f(zz)));
   }
 }
 
@@ -921,22 +936,24 @@ __global__ __launch_bounds__(NW * 64) void ln_gate_fwdc_kernel(const float* __re
                                                                int L, int npos_blocks) {
   constexpr int LPW = 64 / PW, TPP = LPW * NW;
   __shared__ float sstat[2][NW][PW];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int b = blockIdx.x / npos_blocks, pb = blockIdx.x % npos_blocks;
   const int pl = lane % PW, p = pb * PW + pl;
-  const int ck = wv * LPW + lane / PW;
+  const int lg = lane / PW, ck = wv * LPW + lg;
   const bool ok = p < L;
-  const float* mp = m + (int64_t)b * m_sb + p;
-  const float* zp = z + (int64_t)b * z_sb + p;
+  const float* mb = m + (int64_t)b * m_sb;
+  const float* zb = z + (int64_t)b * z_sb;
+  const int om = ok ? (lg * (int)m_sd + p) * 4 : kOOB, oz = ok ? (lg * (int)z_sd + p) * 4 : kOOB;
   float mv[CPL], zv[CPL], s1 = 0.f;
 #pragma unroll
   for (int k = 0; k < CPL; ++k) {
-    const int d = ck + k * TPP;
-    const bool in = ok && d < D;
-    mv[k] = in ? mp[d * m_sd] : 0.f;
-    zv[k] = in ? zp[d * z_sd] : 0.f;
-    s1 += mv[k];
+    const int d0 = wv * LPW + k * TPP;                        // first channel row of this wave's step k (wave-uniform)
+    const bool in = d0 + lg < D;
+    mv[k] = ldb(rows_rsrc(mb, d0, m_sd, LPW, L), in ? om : kOOB);
+    zv[k] = ldb(rows_rsrc(zb, d0, z_sd, LPW, L), in ? oz : kOOB);
   }
+#pragma unroll
+  for (int k = 0; k < CPL; ++k) s1 += mv[k];
   s1 = pos_sum<PW>(s1);
   if (lane < PW) sstat[0][wv][pl] = s1;
   __syncthreads();
@@ -957,19 +974,18 @@ __global__ __launch_bounds__(NW * 64) void ln_gate_fwdc_kernel(const float* __re
 #pragma unroll
   for (int w = 0; w < NW; ++w) var += sstat[1][w][pl];
   const float rstd = __builtin_amdgcn_rsqf(var / D + eps);
-  if (!ok) return;
-  if (ck == 0) {
+  if (ok && ck == 0) {
     mu_out[(int64_t)b * L + p] = mu;
     rstd_out[(int64_t)b * L + p] = rstd;
   }
-  float* yp = y + (int64_t)b * y_sb + p;
+  float* yb = y + (int64_t)b * y_sb;
+  const int oy = ok ? (lg * (int)y_sd + p) * 4 : kOOB;
+  const rsrc_t rgam = make_rsrc(gamma, (int64_t)D * 4), rbet = make_rsrc(beta, (int64_t)D * 4);
 #pragma unroll
   for (int k = 0; k < CPL; ++k) {
-    const int d = ck + k * TPP;
-    if (d < D) {
-      const float n = (mv[k] - mu) * rstd * gamma[d] + beta[d];
-      yp[d * y_sd] = n * (zv[k] * sigmoid_f(zv[k]));
-    }
+    const int d0 = wv * LPW + k * TPP, d = d0 + lg;          // d >= D: gamma / beta read 0, the store is dropped
+    const float n = (mv[k] - mu) * rstd * ldb(rgam, d * 4) + ldb(rbet, d * 4);
+    stb(rows_rsrc(yb, d0, y_sd, LPW, L), d < D ? oy : kOOB, n * (zv[k] * sigmoid_f(zv[k])));
   }
 }
 
@@ -983,58 +999,79 @@ __global__ __launch_bounds__(NW * 64) void ln_gate_bwdc_kernel(const float* __re
                                                                float* __restrict__ dz, int64_t dz_sb, int64_t dz_sd,
                                                                float* __restrict__ ws, int D, int L, int npos_blocks) {
   constexpr int LPW = 64 / PW, TPP = LPW * NW;
+  constexpr int NGB = (2 * CPL * TPP + NW * 64 - 1) / (NW * 64);   // gamma | beta values a thread carries into the LDS
   __shared__ float sstat[2][NW][PW];
-  extern __shared__ float sred[];                       // [2*D]: dgamma | dbeta of this workgroup
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  extern __shared__ float sred[];                       // [2*D]: dgamma | dbeta of this workgroup, then [2*D]: gamma | beta
+  float* sgb = sred + 2 * D;
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int b = blockIdx.x / npos_blocks, pb = blockIdx.x % npos_blocks;
   const int pl = lane % PW, p = pb * PW + pl;
-  const int ck = wv * LPW + lane / PW;
+  const int lg = lane / PW, ck = wv * LPW + lg;
   const bool ok = p < L;
-  const float* mp = m + (int64_t)b * m_sb + p;
-  const float* gp = dy + (int64_t)b * g_sb + p;
-  const float* zp = z + (int64_t)b * z_sb + p;
-  const float mu = ok ? mu_in[(int64_t)b * L + p] : 0.f, rstd = ok ? rstd_in[(int64_t)b * L + p] : 0.f;
-  for (int i = threadIdx.x; i < 2 * D; i += NW * 64) sred[i] = 0.f;
+  const float* mb = m + (int64_t)b * m_sb;
+  const float* gb = dy + (int64_t)b * g_sb;
+  const float* zb = z + (int64_t)b * z_sb;
+  const rsrc_t rst = make_rsrc(mu_in + (int64_t)b * L, (int64_t)L * 4), rrs = make_rsrc(rstd_in + (int64_t)b * L, (int64_t)L * 4);
+  const float mu = ldb(rst, ok ? p * 4 : kOOB), rstd = ldb(rrs, ok ? p * 4 : kOOB);
+  // gamma | beta of all channels once per workgroup (an offset beyond D * 4 — also a negative one — reads 0)
+  const rsrc_t rgam = make_rsrc(gamma, (int64_t)D * 4), rbet = make_rsrc(beta, (int64_t)D * 4);
+  float gbv[NGB];
+#pragma unroll
+  for (int j = 0; j < NGB; ++j) {
+    const int i = threadIdx.x + j * NW * 64;
+    gbv[j] = ldb(rgam, i * 4) + ldb(rbet, (i - D) * 4);
+  }
+  const int om = ok ? (lg * (int)m_sd + p) * 4 : kOOB, og = ok ? (lg * (int)g_sd + p) * 4 : kOOB,
+            oz = ok ? (lg * (int)z_sd + p) * 4 : kOOB;
   float gv[CPL], zv[CPL], xh[CPL], c1 = 0.f, c2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < CPL; ++k) {
+    const int d0 = wv * LPW + k * TPP;                        // first channel row of this wave's step k (wave-uniform)
+    const bool in = d0 + lg < D;
+    zv[k] = ldb(rows_rsrc(zb, d0, z_sd, LPW, L), in ? oz : kOOB);
+    gv[k] = ldb(rows_rsrc(gb, d0, g_sd, LPW, L), in ? og : kOOB);
+    xh[k] = ldb(rows_rsrc(mb, d0, m_sd, LPW, L), in ? om : kOOB);
+  }
+#pragma unroll
+  for (int j = 0; j < NGB; ++j) {
+    const int i = threadIdx.x + j * NW * 64;
+    if (i < 2 * D) { sgb[i] = gbv[j]; sred[i] = 0.f; }
+  }
+  __syncthreads();
 #pragma unroll
   for (int k = 0; k < CPL; ++k) {
     const int d = ck + k * TPP;
     const bool in = ok && d < D;
-    zv[k] = in ? zp[d * z_sd] : 0.f;
-    gv[k] = in ? gp[d * g_sd] : 0.f;
-    xh[k] = in ? (mp[d * m_sd] - mu) * rstd : 0.f;
-    const float dn = in ? gv[k] * (zv[k] * sigmoid_f(zv[k])) * gamma[d] : 0.f;
+    xh[k] = in ? (xh[k] - mu) * rstd : 0.f;
+    const float dn = gv[k] * (zv[k] * sigmoid_f(zv[k])) * sgb[d < D ? d : 0];       // gv = 0 where there is no work
     c1 += dn;
     c2 = fmaf(dn, xh[k], c2);
   }
   c1 = pos_sum<PW>(c1);
   c2 = pos_sum<PW>(c2);
   if (lane < PW) { sstat[0][wv][pl] = c1; sstat[1][wv][pl] = c2; }
-  __syncthreads();                                       // also orders the zero-fill of sred before the atomics below
+  __syncthreads();
   c1 = 0.f; c2 = 0.f;
 #pragma unroll
   for (int w = 0; w < NW; ++w) { c1 += sstat[0][w][pl]; c2 += sstat[1][w][pl]; }
   c1 /= D; c2 /= D;
-  float* dmp = dm + (int64_t)b * dm_sb + p;
-  float* dzp = dz + (int64_t)b * dz_sb + p;
+  float* dmb = dm + (int64_t)b * dm_sb;
+  float* dzb = dz + (int64_t)b * dz_sb;
+  const int odm = ok ? (lg * (int)dm_sd + p) * 4 : kOOB, odz = ok ? (lg * (int)dz_sd + p) * 4 : kOOB;
 #pragma unroll
   for (int k = 0; k < CPL; ++k) {
-    const int d = ck + k * TPP;
-    float pg = 0.f, pb_ = 0.f;
-    if (ok && d < D) {
-      const float zz = zv[k], s_ = sigmoid_f(zz), sz = zz * s_;
-      const float gm = gamma[d];
-      const float n = xh[k] * gm + beta[d];
-      const float dn = gv[k] * sz;
-      dzp[d * dz_sd] = gv[k] * n * (s_ * (1.f + zz * (1.f - s_)));
-      dmp[d * dm_sd] = rstd * (dn * gm - c1 - xh[k] * c2);
-      pg = dn * xh[k];
-      pb_ = dn;
-    }
+    const int d0 = wv * LPW + k * TPP, d = d0 + lg, dc = d < D ? d : 0;
+    const bool in = ok && d < D;
+    const float zz = zv[k], s_ = sigmoid_f(zz), sz = zz * s_;
+    const float gm = sgb[dc];
+    const float n = xh[k] * gm + sgb[D + dc];
+    const float dn = gv[k] * sz;                          // 0 where there is no work: gv = 0
+    stb(rows_rsrc(dzb, d0, dz_sd, LPW, L), d < D ? odz : kOOB, gv[k] * n * (s_ * (1.f + zz * (1.f - s_))));
+    stb(rows_rsrc(dmb, d0, dm_sd, LPW, L), d < D ? odm : kOOB, rstd * (dn * gm - c1 - xh[k] * c2));
     // sum over the PW positions of this wave that share channel d (lanes with equal lane / PW): xor over the low bits
-    pg = low_sum<PW>(pg);
-    pb_ = low_sum<PW>(pb_);
-    if (pl == 0 && d < D) {          // every channel belongs to exactly one (wave, lane group): plain stores would do, too
+    const float pg = low_sum<PW>(in ? dn * xh[k] : 0.f);
+    const float pb_ = low_sum<PW>(in ? dn : 0.f);
+    if (pl == 0 && d < D) {          // every channel belongs to exactly one (wave, lane group)
       sred[d] = pg;
       sred[D + d] = pb_;
     }
@@ -1096,6 +1133,11 @@ inline LnPlan plan_ln(int batch, int D, int L, bool bwd) {
   return pl;
 }
 
+inline bool ln_offsets_fit(int batch, int L, std::initializer_list<int64_t> channel_strides) {
+  for (int64_t sd : channel_strides)
+    if (sd < 0 || 15 * sd + (int64_t)batch * L >= (1ll << 29)) return false;
+  return true;
+}
 inline bool ln_flat() { static const bool on = [] { const char* e = getenv("MM_LN_FLAT"); return e ? atoi(e) != 0 : true; }(); return on; }   // A/B switch
 
 #define MM_LN_ARGS_F m, m_sb, m_sd, z, z_sb, z_sd, gamma, beta, eps, y, y_sb, y_sd, mu, rstd, D, L, npb
@@ -1135,10 +1177,10 @@ int launch_ln_bwdc(const LnPlan& pl, dim3 grid, hipStream_t s, const float* dy, 
                    int64_t m_sb, int64_t m_sd, const float* z, int64_t z_sb, int64_t z_sd, const float* gamma, const float* beta,
                    const float* mu, const float* rstd, float* dm, int64_t dm_sb, int64_t dm_sd, float* dz, int64_t dz_sb,
                    int64_t dz_sd, float* ws, int D, int L, int npb) {
-#define MM_LN_BWDC(NW_, CPL_) hipLaunchKernelGGL((ln_gate_bwdc_kernel<16, NW_, CPL_>), grid, dim3(NW_ * 64), 2 * D * sizeof(float), s, MM_LN_ARGS_B)
-#define MM_LN_BWDC32(CPL_) hipLaunchKernelGGL((ln_gate_bwdc_kernel<32, 8, CPL_>), grid, dim3(512), 2 * D * sizeof(float), s, MM_LN_ARGS_B)
+#define MM_LN_BWDC(NW_, CPL_) hipLaunchKernelGGL((ln_gate_bwdc_kernel<16, NW_, CPL_>), grid, dim3(NW_ * 64), 4 * D * sizeof(float), s, MM_LN_ARGS_B)
+#define MM_LN_BWDC32(CPL_) hipLaunchKernelGGL((ln_gate_bwdc_kernel<32, 8, CPL_>), grid, dim3(512), 4 * D * sizeof(float), s, MM_LN_ARGS_B)
   if (pl.pw == 64) {
-#define MM_LN_BWDC64(CPL_) hipLaunchKernelGGL((ln_gate_bwdc_kernel<64, 4, CPL_>), grid, dim3(256), 2 * D * sizeof(float), s, MM_LN_ARGS_B)
+#define MM_LN_BWDC64(CPL_) hipLaunchKernelGGL((ln_gate_bwdc_kernel<64, 4, CPL_>), grid, dim3(256), 4 * D * sizeof(float), s, MM_LN_ARGS_B)
     if (pl.cpl == 16) MM_LN_BWDC64(16); else if (pl.cpl == 24) MM_LN_BWDC64(24); else MM_LN_BWDC64(32);
 #undef MM_LN_BWDC64
   } else if (pl.pw == 32) {
@@ -1274,6 +1316,8 @@ int mm_ln_gate_fwd(const float* m, int64_t m_sb, int64_t m_sd, const float* z, i
   const int pw = pl.pw, npb = (L + pl.ppb - 1) / pl.ppb;
   const dim3 grid(batch * npb), blk(256);
   hipStream_t s = (hipStream_t)stream;
+  // 32-bit byte offsets inside one step of the register-resident kernels (rows_rsrc): up to 16 channel rows and one position row
+  if ((pl.nw > 0 || pl.cpl > 0) && !ln_offsets_fit(batch, L, {m_sd, z_sd, y_sd})) return MM_ERR_SHAPE;
   if (pl.nw > 0) {
     // channel-major planes (batch stride = L everywhere): the positions of ALL batch items are one contiguous, 128-B aligned row of
     // batch*L floats per channel.  Tiled per item, a 16-position run starts at byte 4*(b*L + 16*k) — at L = 196 / 49 three out of
@@ -1303,6 +1347,7 @@ int mm_ln_gate_bwd(const float* dy, int64_t dy_sb, int64_t dy_sd, const float* m
   const int pw = pl.pw, npb = (L + pl.ppb - 1) / pl.ppb;
   const dim3 grid(batch * npb), blk(256);
   hipStream_t s = (hipStream_t)stream;
+  if (pl.nw > 0 && !ln_offsets_fit(batch, L, {dy_sd, m_sd, z_sd, dm_sd, dz_sd})) return MM_ERR_SHAPE;
   if (pl.nw > 0) {
     // flattened position row for channel-major planes (see mm_ln_gate_fwd); the grid — and with it the number of partial rows in
     // ws, mm_ln_gate_rows — is unchanged: surplus workgroups contribute zero rows
