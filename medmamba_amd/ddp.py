@@ -91,6 +91,8 @@ class GradSync:
         self.stats = dict(buckets=0, early=0)
         self._pending = []              # buckets in flight: (flat, grads, work)
         self._launched = set()
+        self._hold = False              # inside no_sync()
+        self._stale = False             # this step's forward saw gradients of an earlier backward: no early launches
         self._hooks = []
         self.buckets = [self.params]
         if self.world > 1:
@@ -126,11 +128,17 @@ class GradSync:
         def pre_hook(mod, args):
             x = args[0]
             if self.world > 1 and torch.is_grad_enabled() and isinstance(x, torch.Tensor) and x.requires_grad:
+                # "gradient present" only means "gradient final" when the step started without gradients (zero_grad(set_to_none=True),
+                # train.py:281): with gradients left from an earlier backward (accumulation over micro-batches) nothing goes out early
+                if any(b[0].grad is not None or b[-1].grad is not None for b in self.buckets):
+                    self._stale = True
                 x.register_hook(lambda g: self._boundary(closes))
         return pre_hook
 
     def _boundary(self, closes):
         """Runs inside backward (autograd thread), when the gradient of a stage's input has been computed."""
+        if self._stale or self._hold:
+            return None
         for n in closes:
             if n not in self._launched and all(p.grad is not None for p in self.buckets[n]):
                 self._launch(n, early=True)
@@ -155,7 +163,7 @@ class GradSync:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
         work = dist.all_reduce(flat, group=self.group, async_op=True)
-        self._pending.append((flat, grads, work, ev))
+        self._pending.append((flat, grads, work, ev, [g._version for g in grads] if early else None))
         self._launched.add(n)
         self.last["early"] += int(early)
 
@@ -165,15 +173,34 @@ class GradSync:
         for n in range(len(self.buckets)):
             if n not in self._launched:
                 self._launch(n, early=False)
-        for flat, grads, work, ev in self._pending:
+        for flat, grads, work, ev, versions in self._pending:
             work.wait()                                  # device tensors: the current stream waits for the collective
+            if versions is not None and versions != [g._version for g in grads]:
+                self._pending, self._launched, self.last, self._stale = [], set(), dict(buckets=0, early=0), False
+                raise RuntimeError("GradSync: gradients changed after their bucket's all-reduce had started (a second backward without "
+                                   "sync() in between?) — run the backward passes of all but the last micro-batch under no_sync()")
             if ev is not None:
                 ev[1].record()
                 self.events.append(ev)
             flat.mul_(1.0 / self.world)
             torch._foreach_copy_(grads, list(torch._utils._unflatten_dense_tensors(flat, grads)))
         self.stats = dict(buckets=len(self._pending), early=self.last["early"])      # of the step just finished
-        self._pending, self._launched, self.last = [], set(), dict(buckets=0, early=0)
+        self._pending, self._launched, self.last, self._stale = [], set(), dict(buckets=0, early=0), False
+
+    def no_sync(self):
+        """Context for gradient accumulation: backward passes inside it start no all-reduce (the gradients stay local); the last
+        micro-batch runs outside it and is followed by sync() as usual — it sees the accumulated gradients at its forward pass and
+        therefore sends everything after backward (one launch per bucket, nothing early)."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def ctx():
+            prev, self._hold = self._hold, True
+            try:
+                yield
+            finally:
+                self._hold = prev
+        return ctx()
 
     def allreduce_ms(self):
         """Sum of the device time between the start of each collective and the point where the step waited for it, over the calls

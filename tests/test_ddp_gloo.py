@@ -60,8 +60,25 @@ def _worker(rank, world, port, outdir, mode):
             sync()
             stats.append(dict(sync.stats))
     grads = {k: p.grad.clone() for k, p in net.named_parameters()}
-    torch.save(dict(grads=grads, loss=float(loss), stats=stats, nbuckets=0 if sync is None else len(sync.buckets)),
-               os.path.join(outdir, f"r{rank}.pt"))
+    accum, accum_stats, misuse = {}, None, ""
+    if sync is not None:               # gradient accumulation: two micro-batches, one exchange
+        net.zero_grad(set_to_none=True)
+        with sync.no_sync():
+            torch.nn.functional.cross_entropy(model(x), y).backward()
+        torch.nn.functional.cross_entropy(model(x), y).backward()
+        sync()
+        accum = {k: p.grad.clone() for k, p in net.named_parameters()}
+        accum_stats = dict(sync.stats)
+        if mode == "bucketed":         # the misuse the version check is there for: a second backward after an early launch, no no_sync()
+            net.zero_grad(set_to_none=True)
+            torch.nn.functional.cross_entropy(model(x), y).backward()
+            torch.nn.functional.cross_entropy(model(x), y).backward()
+            try:
+                sync()
+            except RuntimeError as e:
+                misuse = str(e)
+    torch.save(dict(grads=grads, accum=accum, accum_stats=accum_stats, misuse=misuse, loss=float(loss), stats=stats,
+                    nbuckets=0 if sync is None else len(sync.buckets)), os.path.join(outdir, f"r{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -83,8 +100,14 @@ def test_ddp_gradients_match_single_process(tmp_path, monkeypatch, mode):
         assert torch.equal(r0["grads"][k], r1["grads"][k]), k          # all-reduced: identical on both ranks
     if mode == "bucketed":             # two stages -> two buckets; the last stage's went out DURING backward, in both passes
         assert r0["nbuckets"] == 2 and r0["stats"] == [dict(buckets=2, early=1)] * 2 == r1["stats"], r0["stats"]
+        assert "no_sync" in r0["misuse"] and "no_sync" in r1["misuse"]
     elif mode == "flat":
         assert r0["nbuckets"] == 1 and r0["stats"] == [dict(buckets=1, early=0)] * 2
+    if mode != "torch":                # accumulation over two equal micro-batches under no_sync(): twice the gradient, nothing early
+        assert r0["accum_stats"]["early"] == 0
+        for k in r0["grads"]:
+            assert torch.allclose(r0["accum"][k], 2 * r0["grads"][k], rtol=1e-5, atol=1e-7), k
+            assert torch.equal(r0["accum"][k], r1["accum"][k]), k
     net = _build_model()
     g = torch.Generator().manual_seed(100)
     x = torch.randn(4, 3, 16, 16, generator=g)
