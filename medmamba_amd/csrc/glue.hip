@@ -149,7 +149,9 @@ struct DivMod {
 // per thread, ~5 KB per CU where ~40 KB are needed to cover HBM latency: the strip kernels ran at 3.1-3.3 TB/s; batched: fused
 // backward 198.6 -> 140.6 us at 56x56 (4.4 TB/s), 93.0 -> 63.7 us at 28x28, forward 58.5 -> 52.5 / 31.5 -> 29.1 us.  The
 // one-wavefront-per-plane kernels below keep their simple loops: with seven descriptors and 28 loads per lane up front they got
-// SLOWER, 44.1 -> 53.2 us at 14x14 — many small waves already keep enough loads in flight there.)
+// SLOWER, 44.1 -> 53.2 us at 14x14 — many small waves already keep enough loads in flight there.  Nor are they load-bound at all:
+// one b128 load per lane and operand plane (a 14x14 plane is 49 float4), parked in LDS in memory order, moved the fused backward
+// 41.8 -> 41.2 us and the forward 22.1 -> 21.6 us — ~520 VALU / LDS instructions per plane and wave are what these kernels cost.)
 __device__ __forceinline__ float ldb(rsrc_t r, int off) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
 }
