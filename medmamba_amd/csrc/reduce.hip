@@ -25,18 +25,22 @@ __global__ __launch_bounds__(256) void sum_lead_kernel(const float* __restrict__
   float acc[W];
 #pragma unroll
   for (int w = 0; w < W; ++w) acc[w] = 0.f;
-  const float* p = src + i0;
+  const float* p = src + (ok ? i0 : 0);
   for (int j = jp; j < nlead; j += 8 * PY) {
     float v[8][W];
+    // unconditional loads from a clamped (always valid) row, the value dropped afterwards: a load behind `in ? ... : 0` is a branch
+    // around the load and a wait before the next one — one load in flight per thread instead of eight
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int jj = j + u * PY;
       const bool in = ok && jj < nlead;
+      const int64_t row = (int64_t)(jj < nlead ? jj : nlead - 1) * lead_stride;
       if constexpr (VEC) {
-        const float4 t = in ? *reinterpret_cast<const float4*>(p + (int64_t)jj * lead_stride) : make_float4(0.f, 0.f, 0.f, 0.f);
-        v[u][0] = t.x; v[u][1] = t.y; v[u][2] = t.z; v[u][3] = t.w;
+        const float4 t = *reinterpret_cast<const float4*>(p + row);
+        v[u][0] = in ? t.x : 0.f; v[u][1] = in ? t.y : 0.f; v[u][2] = in ? t.z : 0.f; v[u][3] = in ? t.w : 0.f;
       } else {
-        v[u][0] = in ? p[(int64_t)jj * lead_stride] : 0.f;
+        const float t = p[row];
+        v[u][0] = in ? t : 0.f;
       }
     }
 #pragma unroll

@@ -12,7 +12,9 @@ for D, R in [(96, 3), (192, 6), (384, 12), (768, 24)]:
     P = torch.empty(n, device=dev); G = torch.empty(n, device=dev); dP = torch.randn(n, device=dev)
     st = _lib.raw_stream()
     def f(): lib.mm_ss2d_pack_fwd(*[t.data_ptr() for t in srcs], P.data_ptr(), D, C, R, N, st)
-    def b(): lib.mm_ss2d_pack_bwd(dP.data_ptr(), P.data_ptr(), G.data_ptr(), D, C, R, N, st)
+    Bz = 64; parts = torch.randn(Bz, lib.mm_ss2d_pack_parts_size(D, C, R, N), device=dev)      # per-batch-item dA | dD | dbias partials
+    def b(): lib.mm_ss2d_pack_bwd(dP.data_ptr(), P.data_ptr(), parts.data_ptr(), G.data_ptr(), D, C, R, N, Bz, None, 0, None, None, 0, 0,
+                                  None, st)
     for fn, name in ((f, "fwd"), (b, "bwd")):
         for _ in range(5): fn()
         torch.cuda.synchronize()
