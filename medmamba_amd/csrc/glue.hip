@@ -1395,26 +1395,29 @@ __device__ __forceinline__ void ln_half_fwd_body(int vblk, int vgrid, const floa
                                                  float* __restrict__ mu_out, float* __restrict__ rstd_out,
                                                  int64_t nrows, int C, int C2) {
   constexpr int RPW = 64 / TPR;
-  const int lane = threadIdx.x & 63, lr = lane % TPR;
-  const int64_t wave_global = (int64_t)vblk * 4 + (threadIdx.x >> 6), nwaves = (int64_t)vgrid * 4;
+  const int lane = threadIdx.x & 63, lr = lane % TPR, lrow = lane / TPR;
+  const int64_t wave_global = (int64_t)vblk * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = (int64_t)vgrid * 4;
+  const rsrc_t rgam = make_rsrc(gamma, (int64_t)C2 * 4), rbet = make_rsrc(beta, (int64_t)C2 * 4);
   float gm[kLnNV], bt[kLnNV];
 #pragma unroll
   for (int k = 0; k < kLnNV; ++k) {
-    const int c = lr + k * TPR;
-    gm[k] = c < C2 ? gamma[c] : 0.f;
-    bt[k] = c < C2 ? beta[c] : 0.f;
+    gm[k] = ldb(rgam, (lr + k * TPR) * 4);           // beyond C2: 0
+    bt[k] = ldb(rbet, (lr + k * TPR) * 4);
   }
   for (int64_t rg = wave_global; rg * RPW < nrows; rg += nwaves) {
-    const int64_t row = rg * RPW + lane / TPR;
+    const int64_t row0 = rg * RPW, row = row0 + lrow;               // row0: wave-uniform
     const bool rok = row < nrows;
-    const float* xr = inp + row * C + C2;
+    // the RPW rows of this wave through one descriptor (no branch around a load: all kLnNV loads of a lane in flight, §4.4)
+    const int nr = (int)(nrows - row0 < RPW ? nrows - row0 : RPW);
+    const rsrc_t rx = make_rsrc(inp + row0 * C + C2, ((int64_t)(nr - 1) * C + C2) * 4);
     float x[kLnNV], s = 0.f;
 #pragma unroll
     for (int k = 0; k < kLnNV; ++k) {
       const int c = lr + k * TPR;
-      x[k] = (rok && c < C2) ? xr[c] : 0.f;
-      s += x[k];
+      x[k] = ldb(rx, (rok && c < C2) ? (lrow * C + c) * 4 : kOOB);
     }
+#pragma unroll
+    for (int k = 0; k < kLnNV; ++k) s += x[k];
     const float mean = row_sum<TPR>(s) / C2;
     float v = 0.f;
 #pragma unroll
@@ -1442,25 +1445,39 @@ __device__ __forceinline__ void ln_half_bwd_body(int vblk, int vgrid, const floa
                                                  float* __restrict__ dinp, float* __restrict__ ws, int64_t nrows, int C,
                                                  int C2) {
   constexpr int RPW = 64 / TPR;
-  const int lane = threadIdx.x & 63, lr = lane % TPR;
-  const int64_t wave_global = (int64_t)vblk * 4 + (threadIdx.x >> 6), nwaves = (int64_t)vgrid * 4;
+  const int lane = threadIdx.x & 63, lr = lane % TPR, lrow = lane / TPR;
+  const int64_t wave_global = (int64_t)vblk * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = (int64_t)vgrid * 4;
+  const rsrc_t rgam = make_rsrc(gamma, (int64_t)C2 * 4);
   float gm[kLnNV], ag[kLnNV], ab[kLnNV];
 #pragma unroll
   for (int k = 0; k < kLnNV; ++k) {
-    gm[k] = (lr + k * TPR < C2) ? gamma[lr + k * TPR] : 0.f;
+    gm[k] = ldb(rgam, (lr + k * TPR) * 4);           // beyond C2: 0
     ag[k] = 0.f; ab[k] = 0.f;
   }
   for (int64_t rg = wave_global; rg * RPW < nrows; rg += nwaves) {
-    const int64_t row = rg * RPW + lane / TPR;
+    const int64_t row0 = rg * RPW, row = row0 + lrow;               // row0: wave-uniform
     const bool rok = row < nrows;
-    const float mean = rok ? mu_in[row] : 0.f, rstd = rok ? rstd_in[row] : 0.f;
-    float xh[kLnNV], g[kLnNV], s1 = 0.f, s2 = 0.f;
+    // the RPW rows of this wave through one descriptor per operand: 2-3 x kLnNV loads of a lane in flight together (§4.4)
+    const int nr = (int)(nrows - row0 < RPW ? nrows - row0 : RPW);
+    const int64_t half = ((int64_t)(nr - 1) * C + C2) * 4;
+    const rsrc_t rd = make_rsrc(drn + row0 * C2, (int64_t)nr * C2 * 4), rx = make_rsrc(inp + row0 * C + C2, half),
+                 rr = make_rsrc(dres ? dres + row0 * C + C2 : nullptr, dres ? half : 0), rst = make_rsrc(mu_in + row0, (int64_t)nr * 4),
+                 rrs = make_rsrc(rstd_in + row0, (int64_t)nr * 4);
+    const float mean = ldb(rst, lrow * 4), rstd = ldb(rrs, lrow * 4);       // rows beyond nrows: 0
+    float xh[kLnNV], g[kLnNV], dv[kLnNV], rv[kLnNV], s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int k = 0; k < kLnNV; ++k) {
       const int c = lr + k * TPR;
       const bool ok = rok && c < C2;
-      const float d = ok ? drn[row * C2 + c] : 0.f;
-      xh[k] = ok ? (inp[row * C + C2 + c] - mean) * rstd : 0.f;
+      dv[k] = ldb(rd, ok ? (lrow * C2 + c) * 4 : kOOB);
+      xh[k] = ldb(rx, ok ? (lrow * C + c) * 4 : kOOB);
+      rv[k] = ldb(rr, ok ? (lrow * C + c) * 4 : kOOB);
+    }
+#pragma unroll
+    for (int k = 0; k < kLnNV; ++k) {
+      const bool ok = rok && lr + k * TPR < C2;
+      const float d = dv[k];
+      xh[k] = ok ? (xh[k] - mean) * rstd : 0.f;
       g[k] = d * gm[k];
       s1 += g[k];
       s2 = fmaf(g[k], xh[k], s2);
@@ -1472,7 +1489,7 @@ __device__ __forceinline__ void ln_half_bwd_body(int vblk, int vgrid, const floa
 #pragma unroll
       for (int k = 0; k < kLnNV; ++k) {
         const int c = lr + k * TPR;
-        if (c < C2) dinp[row * C + C2 + c] = rstd * (g[k] - c1 - xh[k] * c2) + (dres ? dres[row * C + C2 + c] : 0.f);
+        if (c < C2) dinp[row * C + C2 + c] = rstd * (g[k] - c1 - xh[k] * c2) + rv[k];
       }
     }
   }
@@ -1504,13 +1521,18 @@ __device__ __forceinline__ void half_transpose_body(int vblk, const float* __res
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const int nbp = (P + 31) / 32, nbi = (C2 + 31) / 32;
   const int p0 = (vblk % nbp) * 32, i0 = ((vblk / nbp) % nbi) * 32, b = vblk / (nbp * nbi);
+  // tile loads through a descriptor that starts at the tile (32-bit offsets for any tensor size), no branch around a load: the four
+  // loads of a thread are in flight together (§4.4)
   if constexpr (!REV) {
-    const float* s = src + (int64_t)b * P * C;
+    const rsrc_t rs = make_rsrc(src + ((int64_t)b * P + p0) * C + i0, ((int64_t)(min(32, P - p0) - 1) * C + min(32, C2 - i0)) * 4);
+    float v[4];
 #pragma unroll
-    for (int r = ty; r < 32; r += 8) {           // rows p, lanes along i
-      const int p = p0 + r, i = i0 + tx;
-      tile[r][tx] = (p < P && i < C2) ? s[(int64_t)p * C + i] : 0.f;
+    for (int q = 0; q < 4; ++q) {                // rows p, lanes along i
+      const int r = ty + 8 * q;
+      v[q] = ldb(rs, (p0 + r < P && i0 + tx < C2) ? (r * C + tx) * 4 : kOOB);
     }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) tile[ty + 8 * q][tx] = v[q];
     __syncthreads();
     float* d = dst + (int64_t)b * C2 * P;
 #pragma unroll
@@ -1521,19 +1543,24 @@ __device__ __forceinline__ void half_transpose_body(int vblk, const float* __res
       if (i < C2 && p < P) d[(int64_t)i * P + p] = add ? fmaf(tile[tx][r], add[i], add[C2 + i]) : tile[tx][r];
     }
   } else {
-    const float* s = src + (int64_t)b * C2 * P;
+    const rsrc_t rs = make_rsrc(src + ((int64_t)b * C2 + i0) * P + p0, ((int64_t)(min(32, C2 - i0) - 1) * P + min(32, P - p0)) * 4);
+    const rsrc_t ra = make_rsrc(add ? add + ((int64_t)b * P + p0) * C + i0 : nullptr,
+                                add ? ((int64_t)(min(32, P - p0) - 1) * C + min(32, C2 - i0)) * 4 : 0);
+    float v[4], av[4];
 #pragma unroll
-    for (int r = ty; r < 32; r += 8) {
-      const int i = i0 + r, p = p0 + tx;
-      tile[r][tx] = (i < C2 && p < P) ? s[(int64_t)i * P + p] : 0.f;
+    for (int q = 0; q < 4; ++q) {
+      const int r = ty + 8 * q;
+      v[q] = ldb(rs, (i0 + r < C2 && p0 + tx < P) ? (r * P + tx) * 4 : kOOB);
+      av[q] = ldb(ra, (p0 + r < P && i0 + tx < C2) ? (r * C + tx) * 4 : kOOB);      // the element this thread stores below
     }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) tile[ty + 8 * q][tx] = v[q];
     __syncthreads();
     float* d = dst + (int64_t)b * P * C;
-    const float* a = add ? add + (int64_t)b * P * C : nullptr;
 #pragma unroll
-    for (int r = ty; r < 32; r += 8) {
-      const int p = p0 + r, i = i0 + tx;
-      if (p < P && i < C2) d[(int64_t)p * C + i] = tile[tx][r] + (a ? a[(int64_t)p * C + i] : 0.f);
+    for (int q = 0; q < 4; ++q) {
+      const int r = ty + 8 * q, p = p0 + r, i = i0 + tx;
+      if (p < P && i < C2) d[(int64_t)p * C + i] = tile[tx][r] + av[q];
     }
   }
 }
