@@ -17,19 +17,23 @@ __global__ __launch_bounds__(256) void im2col3x3_kernel(const float* __restrict_
   // exceed the cap — the deterministic weight gradient of trainer.set_seed runs this at any batch size)
   for (int plane = blockIdx.y; plane < planes; plane += gridDim.y) {
   const int b = plane / C, c = plane - b * C;
-  const float* xp = x + (int64_t)plane * HW;
+  const mm::rsrc_t rx = mm::make_rsrc(x + (int64_t)plane * HW, (int64_t)HW * 4);   // taps outside the image read 0 through the range check:
   // image j = b % gs of group g = b / gs: column block j of the group's (9C) x (gs*HW) matrix
   float* cp = cols + (((int64_t)(b / gs) * 9 * C + (int64_t)c * 9) * gs + (b % gs)) * HW;
   const int64_t tap = (int64_t)gs * HW;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) {
     const int h = i / W, w = i - h * W;
+    float v[9];                                                                       // no branch, nine loads in flight
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll
       for (int s2 = 0; s2 < 3; ++s2) {
         const int hh = h + r - 1, ww = w + s2 - 1;
-        cp[(r * 3 + s2) * tap + i] = (hh >= 0 && hh < H && ww >= 0 && ww < W) ? xp[hh * W + ww] : 0.f;
+        v[r * 3 + s2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+            rx, (hh >= 0 && hh < H && ww >= 0 && ww < W) ? (hh * W + ww) * 4 : mm::kOOB, 0, 0));
       }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) cp[t * tap + i] = v[t];
   }
   }
 }
