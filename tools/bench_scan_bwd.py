@@ -52,7 +52,7 @@ def main():
         if os.environ.get("FWD_VARIANTS"):      # forward kernel in the same operand layouts: FWD_VARIANTS=0,2,4,0x1000004 ...
             fb = ssi.scan_bytes_fwd(Bz, K * D, L, N, K)
             for fv in [int(v, 0) for v in os.environ["FWD_VARIANTS"].split(",")]:
-                for chk in (False, True):
+                for chk in ((False, True) if "FWD_CHK" not in os.environ else (os.environ["FWD_CHK"] == "1",)):
                     runf = lambda: ssi._launch_fwd(u2, delta, A, xb[:, :, R:R + N], xb[:, :, R + N:], Dp, bias, True, chk, fv or 0,
                                                    ssi._CROSS_SHARED)
                     ssi._FWD_VARIANT = fv
