@@ -102,7 +102,9 @@ typedef struct mm_scan_args {
   float* dC;
   float* dD;
   float* ddelta_bias;
-  /* tuning override: 0 = library default; low byte = states-per-lane variant (1,2,4) */
+  /* tuning override: 0 = library default; low byte = states-per-lane variant (1,2,4; forward: 32 = the workgroup-cooperative kernel);
+   * bits 16-23 waves per workgroup; forward: bit 24 / 25 force the register-lean form on / off, bit 26 = every wave stages its own
+   * B / C tile (default where it applies: one shared tile per 4-wave workgroup).  Results do not depend on any of these. */
   int32_t variant;
   /* Cross-scan without materialising it (replaces the stack/transpose/flip/cat of MedMamba.py:256-257 and the
    * flips of :282).  All zero = plain selective_scan_fn semantics.

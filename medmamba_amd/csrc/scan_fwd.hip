@@ -81,7 +81,10 @@ __device__ __forceinline__ float f4get(const float4& v, int i) {
 //       software-pipelined in registers.
 // DT: the dt projection (rank R <= kDtMax) is fused into the staging phase: no (batch, K*D, L) delta tensor is read.
 constexpr int kDtMax = 8;
-template <int NS, bool VEC, bool SP, bool LEAN, bool DT = false>
+// SH (LEAN, 4 waves per workgroup that all belong to one (batch, direction)): the B / C tile is staged ONCE per workgroup — each
+//     wave loads one quarter, one tile ahead — into a double-buffered shared tile, one barrier per tile.  Wave-private staging
+//     asked the L1 for every B / C line four times at once (TCP_PENDING_STALL 50-69 % of the kernel, profiles/r4_fwd_mem_counters_*).
+template <int NS, bool VEC, bool SP, bool LEAN, bool DT = false, bool SH = false>
 __global__ __launch_bounds__(256) void scan_fwd_kernel(const FwdParams p) {
   constexpr int SG = kNState / NS;   // lanes per channel
   constexpr int CH = kWave / SG;     // channels per wave (= 4*NS)
@@ -94,7 +97,9 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(const FwdParams p) {
   constexpr int NBC = 2 * kNState / RPI;          // float4 B/C staging loads per lane per tile
   constexpr int NPBC = LEAN ? 1 : NBC;
   constexpr int kBCS = bcs_of(NS);
-  constexpr int WLDS = 2 * CH * kTileStride + 2 * kTile * kBCS;            // floats of LDS per wave
+  constexpr int WPRIV = 2 * CH * kTileStride, BCSZ = 2 * kTile * kBCS;
+  constexpr int WLDS = SH ? WPRIV : WPRIV + BCSZ;                          // floats of LDS per wave
+  static_assert(!SH || (LEAN && NBC == 4 && !DT), "shared B/C staging: 4 waves x one quarter of a 32-step tile");
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
   const int lane = threadIdx.x & 63;
@@ -116,7 +121,8 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(const FwdParams p) {
   float* wl = smem + wave * WLDS;
   float* s_dl = wl;                                   // [CH][kTileStride]   delta'
   float* s_du = wl + CH * kTileStride;                // [CH][kTileStride]   delta'*u, then y (in place)
-  float* s_bc = wl + 2 * CH * kTileStride;            // [2][kTile][kBCS] B, C: row = position inside the tile, column = state
+  // [2][kTile][kBCS] B, C: row = position inside the tile, column = state.  SH: two such tiles behind the waves' private rows
+  float* s_bc0 = SH ? smem + wpb * WPRIV : wl + 2 * CH * kTileStride;
 
   // ---- recurrence identity: lane -> (channel c, state group g)
   const int c = lane / SG, g = lane % SG;
@@ -171,9 +177,14 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(const FwdParams p) {
     bcoff[k] = (int)(n * ((k >= NBC / 2) ? p.C_sn : p.B_sn)) * 4;
   }
 
+  // SH: this wave's quarter of the tile = pass `wave` of the staging loop below
+  const int n_w = (wave % (NBC / 2)) * RPI + r;
+  const bool isC_w = wave >= NBC / 2;
+  const int bcoff_w = (int)(n_w * (isC_w ? p.C_sn : p.B_sn)) * 4;
   float4 pu[NLD], pd[DT ? 1 : NLD], pbc[NPBC], pdt[DT ? kDtMax : 1];
   auto issue_loads = [&](int t0) {
     const int t = t0 + 4 * q;
+    if constexpr (SH) pbc[0] = load_quad<VEC, VEC>(isC_w ? rC : rB, bcoff_w, t, p.L, rev, true);
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
       pu[i] = load_quad<VEC, VEC>(ru, uoff[i], t, p.L, rev, rvalid[i]);
@@ -236,8 +247,14 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(const FwdParams p) {
       *reinterpret_cast<float4*>(s_dl + off) = dl;
       *reinterpret_cast<float4*>(s_du + off) = du;
     }
+    float* s_bc = SH ? s_bc0 + (tile & 1) * BCSZ : s_bc0;
+    if constexpr (SH) {
+      const float4 v = pbc[0];
+      float* dst = s_bc + ((isC_w ? kTile : 0) + qc) * kBCS + n_w;
+      dst[0] = v.x; dst[QL * kBCS] = v.y; dst[2 * QL * kBCS] = v.z; dst[3 * QL * kBCS] = v.w;
+    }
 #pragma unroll
-    for (int k = 0; k < NBC; ++k) {
+    for (int k = 0; k < (SH ? 0 : NBC); ++k) {
       const int n = (k % (NBC / 2)) * RPI + r;
       const bool isC = k >= NBC / 2;
       const float4 v = LEAN ? load_quad<VEC, VEC>(isC ? rC : rB, bcoff[k], t0 + 4 * q, p.L, rev, true) : pbc[LEAN ? 0 : k];
@@ -254,6 +271,9 @@ __global__ __launch_bounds__(256) void scan_fwd_kernel(const FwdParams p) {
       if (tile > 0) store_tile(t0 - kTile);
     }
     if (tile + 1 < p.ntiles) issue_loads(t0 + kTile);
+    // SH: every quarter of this tile's B / C is in LDS behind this barrier; the other buffer is free again because every wave has
+    // finished the previous tile's recurrence before it got here
+    if constexpr (SH) __syncthreads();
 
     // ---- phase 2: the recurrence over this tile, 4 steps per group
     const int tlen = min(kTile, p.L - t0);
@@ -646,28 +666,33 @@ int launch_wg(const FwdParams& p, int ncw, int nwv, hipStream_t stream) {
   return (int)hipGetLastError();
 }
 
-template <int NS, bool VEC, bool SP, bool LEAN, bool DT = false>
+template <int NS, bool VEC, bool SP, bool LEAN, bool DT = false, bool SH = false>
 int launch(const FwdParams& p, int nblocks, int wpb, hipStream_t stream) {
   constexpr int CH = 4 * NS;
   constexpr int TS = fwd_tile(NS, LEAN) + 4;
-  const size_t lds = sizeof(float) * (size_t)wpb * (2 * CH * TS + 2 * fwd_tile(NS, LEAN) * bcs_of(NS));
+  constexpr size_t bc = 2 * fwd_tile(NS, LEAN) * bcs_of(NS);                  // one B / C tile: per wave, or two per workgroup (SH)
+  const size_t lds = sizeof(float) * ((size_t)wpb * 2 * CH * TS + (SH ? 2 * bc : (size_t)wpb * bc));
   if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute((const void*)scan_fwd_kernel<NS, VEC, SP, LEAN, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)scan_fwd_kernel<NS, VEC, SP, LEAN, DT, SH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   FwdParams q = p;
   q.ntiles = (p.L + fwd_tile(NS, LEAN) - 1) / fwd_tile(NS, LEAN);
-  hipLaunchKernelGGL((scan_fwd_kernel<NS, VEC, SP, LEAN, DT>), dim3(nblocks), dim3(wpb * 64), lds, stream, q);
+  hipLaunchKernelGGL((scan_fwd_kernel<NS, VEC, SP, LEAN, DT, SH>), dim3(nblocks), dim3(wpb * 64), lds, stream, q);
   return (int)hipGetLastError();
 }
 
 template <int NS, bool LEAN>
-int launch_l(const FwdParams& p, int nblocks, int wpb, bool vec, bool sp, hipStream_t stream) {
+int launch_l(const FwdParams& p, int nblocks, int wpb, bool vec, bool sp, bool sh, hipStream_t stream) {
   if (p.dtw != nullptr) return launch<NS, true, true, LEAN, true>(p, nblocks, wpb, stream);   // (checked by the caller: vec && sp)
+  if constexpr (NS == 4 && LEAN) {      // workgroup-shared B / C tile (the softplus forms: what SS2D calls)
+    if (sh && sp) return vec ? launch<4, true, true, true, false, true>(p, nblocks, wpb, stream)
+                             : launch<4, false, true, true, false, true>(p, nblocks, wpb, stream);
+  }
   if (vec) return sp ? launch<NS, true, true, LEAN>(p, nblocks, wpb, stream) : launch<NS, true, false, LEAN>(p, nblocks, wpb, stream);
   return sp ? launch<NS, false, true, LEAN>(p, nblocks, wpb, stream) : launch<NS, false, false, LEAN>(p, nblocks, wpb, stream);
 }
 template <int NS>
-int launch_ns(const FwdParams& p, int nblocks, int wpb, bool vec, bool sp, bool lean, hipStream_t stream) {
-  return lean ? launch_l<NS, true>(p, nblocks, wpb, vec, sp, stream) : launch_l<NS, false>(p, nblocks, wpb, vec, sp, stream);
+int launch_ns(const FwdParams& p, int nblocks, int wpb, bool vec, bool sp, bool lean, bool sh, hipStream_t stream) {
+  return lean ? launch_l<NS, true>(p, nblocks, wpb, vec, sp, sh, stream) : launch_l<NS, false>(p, nblocks, wpb, vec, sp, false, stream);
 }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -742,6 +767,8 @@ int scan_fwd_launch(const mm_scan_args* a, hipStream_t stream, int32_t* plan_out
   bool lean = ns == 4 && p.nwaves_total >= 3 * 1024;
   if (a->variant & (1 << 24)) lean = true;
   if (a->variant & (1 << 25)) lean = false;
+  // the four waves of a workgroup share one B / C tile when they all belong to one (batch, direction); variant bit 26: private tiles
+  const bool sh = lean && ns == 4 && wpb == 4 && p.wpg % 4 == 0 && a->dt_w == nullptr && !(a->variant & (1 << 26));
   // variant low byte 32 (or the default plan, below): the workgroup-cooperative kernel for long sequences with few sequences
   const bool can_wg = vec && sp && a->dt_w == nullptr;
   int wg_ncw = 0, wg_nwv = 0;
@@ -769,9 +796,9 @@ int scan_fwd_launch(const mm_scan_args* a, hipStream_t stream, int32_t* plan_out
   }
   if (use_wg) return launch_wg<true>(p, wg_ncw, wg_nwv, stream);
   switch (ns) {
-    case 1: return launch_ns<1>(p, nblocks, wpb, vec, sp, lean, stream);
-    case 2: return launch_ns<2>(p, nblocks, wpb, vec, sp, lean, stream);
-    default: return launch_ns<4>(p, nblocks, wpb, vec, sp, lean, stream);
+    case 1: return launch_ns<1>(p, nblocks, wpb, vec, sp, lean, false, stream);
+    case 2: return launch_ns<2>(p, nblocks, wpb, vec, sp, lean, false, stream);
+    default: return launch_ns<4>(p, nblocks, wpb, vec, sp, lean, sh, stream);
   }
 }
 

@@ -65,8 +65,8 @@ class _KernelTimer:
 
 
 KERNEL_TIMER = _KernelTimer()
-_BWD_VARIANT = int(__import__("os").environ.get("MM_BWD_VARIANT", "0"))   # tuning knob: waves per workgroup << 16
-_FWD_VARIANT = int(__import__("os").environ.get("MM_FWD_VARIANT", "0"))   # tuning knob: forward kernel / states per lane when a call passes 0
+_BWD_VARIANT = int(__import__("os").environ.get("MM_BWD_VARIANT", "0"), 0)   # tuning knob: waves per workgroup << 16
+_FWD_VARIANT = int(__import__("os").environ.get("MM_FWD_VARIANT", "0"), 0)   # tuning knob: forward kernel / states per lane when a call passes 0
 
 
 def scan_bytes_fwd(batch, dim, L, N, G):
