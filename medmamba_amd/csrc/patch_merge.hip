@@ -24,15 +24,32 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 struct PmGeom { int H, W, C, h2, w2, C4; };   // C4 = C / 4 float4 per source pixel
 
-// source float4 index (inside the NHWC input) of float4 j of output row `row`
-__device__ __forceinline__ int64_t pm_src(const PmGeom& g, int64_t row, int j) {
+__device__ __forceinline__ float ldb1(rsrc_t r, int off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+}
+__device__ __forceinline__ float4 ldb4(rsrc_t r, int off) {
+  return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+}
+__device__ __forceinline__ void stb4(rsrc_t r, int off, float4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), r, off, 0, 0);
+}
+// Round 4: the rows of these kernels go through buffer descriptors that start at the row (wave-uniform 64-bit base, 32-bit lane
+// offsets, kOOB for lanes beyond the row): no branch around a load, so the NV (x 2) loads of a lane are in flight together; the
+// position of a lane's float4 inside the 2x2 gather does not depend on the row and is computed once; the row index is wave-uniform
+// (scalar divisions); gamma / beta stay in registers.  (Before: one conditional load at a time, three 64-bit vector divisions per
+// float4, 4 wavefronts per CU — 2.2 TB/s on the 56x56 -> 28x28 merge.)
+// byte offset of float4 j of ANY output row relative to the row's first source pixel (2*h2i, 2*w2i)
+__device__ __forceinline__ int pm_lane_off(const PmGeom& g, int j) {
   const int s = j / g.C4, o = j - s * g.C4;
+  return (((s & 1) * g.W + (s >> 1)) * g.C4 + o) * 16;
+}
+// float4 index of the first source pixel of output row `row` (wave-uniform)
+__device__ __forceinline__ int64_t pm_row_base(const PmGeom& g, int64_t row) {
   const int w2i = (int)(row % g.w2);
   const int64_t t = row / g.w2;
   const int h2i = (int)(t % g.h2);
   const int64_t b = t / g.h2;
-  const int hh = 2 * h2i + (s & 1), ww = 2 * w2i + (s >> 1);
-  return ((b * g.H + hh) * g.W + ww) * (int64_t)g.C4 + o;
+  return ((b * g.H + 2 * h2i) * g.W + 2 * w2i) * (int64_t)g.C4;
 }
 
 template <int NV>
@@ -41,17 +58,26 @@ __global__ __launch_bounds__(256) void patch_merge_ln_fwd_kernel(const float4* _
                                                                  float* __restrict__ mu_out, float* __restrict__ rstd_out,
                                                                  int64_t nrows, PmGeom g) {
   const int lane = threadIdx.x & 63;
-  const int64_t wave_global = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+  const int64_t wave_global = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
   const float inv_n = 1.f / (4 * g.C);
+  const rsrc_t rgam = make_rsrc(gamma, (int64_t)g.C * 16), rbet = make_rsrc(beta, (int64_t)g.C * 16);
+  const int64_t span = ((int64_t)(g.W + 1) * g.C4 + g.C4) * 16;      // two pixel rows of the 2x2 gather, from its first pixel
+  float4 gm[NV], bt[NV];
+  int xoff[NV];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int j = lane + 64 * k;
+    gm[k] = ldb4(rgam, j * 16); bt[k] = ldb4(rbet, j * 16);          // beyond the row: 0
+    xoff[k] = j < g.C ? pm_lane_off(g, j) : kOOB;
+  }
   for (int64_t row = wave_global; row < nrows; row += nwaves) {
+    const rsrc_t rx = make_rsrc(x + pm_row_base(g, row), span), ro = make_rsrc(out + row * g.C, (int64_t)g.C * 16);
     float4 v[NV];
     float s = 0.f;
 #pragma unroll
-    for (int k = 0; k < NV; ++k) {
-      const int j = lane + 64 * k;
-      v[k] = j < g.C ? x[pm_src(g, row, j)] : make_float4(0.f, 0.f, 0.f, 0.f);
-      s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
-    }
+    for (int k = 0; k < NV; ++k) v[k] = ldb4(rx, xoff[k]);
+#pragma unroll
+    for (int k = 0; k < NV; ++k) s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
     const float mean = wave_sum(s) * inv_n;
     float q = 0.f;
 #pragma unroll
@@ -63,14 +89,9 @@ __global__ __launch_bounds__(256) void patch_merge_ln_fwd_kernel(const float4* _
     }
     const float rstd = __builtin_amdgcn_rsqf(wave_sum(q) * inv_n + eps);
 #pragma unroll
-    for (int k = 0; k < NV; ++k) {
-      const int j = lane + 64 * k;
-      if (j < g.C) {
-        const float4 gm = gamma[j], bt = beta[j];
-        out[row * g.C + j] = make_float4((v[k].x - mean) * rstd * gm.x + bt.x, (v[k].y - mean) * rstd * gm.y + bt.y,
-                                         (v[k].z - mean) * rstd * gm.z + bt.z, (v[k].w - mean) * rstd * gm.w + bt.w);
-      }
-    }
+    for (int k = 0; k < NV; ++k)
+      stb4(ro, (lane + 64 * k) * 16, make_float4((v[k].x - mean) * rstd * gm[k].x + bt[k].x, (v[k].y - mean) * rstd * gm[k].y + bt[k].y,
+                                               (v[k].z - mean) * rstd * gm[k].z + bt[k].z, (v[k].w - mean) * rstd * gm[k].w + bt[k].w));
     if (lane == 0) { mu_out[row] = mean; rstd_out[row] = rstd; }
   }
 }
@@ -82,40 +103,45 @@ __global__ __launch_bounds__(256) void patch_merge_ln_bwd_kernel(const float4* _
                                                                  const float* __restrict__ rstd_in, float4* __restrict__ dinp,
                                                                  float4* __restrict__ ws, int64_t nrows, PmGeom g) {
   const int lane = threadIdx.x & 63;
-  const int64_t wave_global = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+  const int64_t wave_global = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
   const float inv_n = 1.f / (4 * g.C);
-  float4 ag[NV], ab[NV];
+  const rsrc_t rgam = make_rsrc(gamma, (int64_t)g.C * 16);
+  const int64_t span = ((int64_t)(g.W + 1) * g.C4 + g.C4) * 16;      // two pixel rows of the 2x2 gather, from its first pixel
+  float4 ag[NV], ab[NV], gm[NV];
+  int xoff[NV];
 #pragma unroll
-  for (int k = 0; k < NV; ++k) { ag[k] = make_float4(0.f, 0.f, 0.f, 0.f); ab[k] = ag[k]; }
+  for (int k = 0; k < NV; ++k) {
+    const int j = lane + 64 * k;
+    ag[k] = make_float4(0.f, 0.f, 0.f, 0.f); ab[k] = ag[k];
+    gm[k] = ldb4(rgam, j * 16);                                      // beyond the row: 0
+    xoff[k] = j < g.C ? pm_lane_off(g, j) : kOOB;
+  }
   for (int64_t row = wave_global; row < nrows; row += nwaves) {
+    const int64_t rb = pm_row_base(g, row);
+    const rsrc_t rx = make_rsrc(x + rb, span), rdx = make_rsrc(dinp + rb, span), rdy = make_rsrc(dy + row * g.C, (int64_t)g.C * 16);
     const float mean = mu_in[row], rstd = rstd_in[row];
-    float4 xh[NV], gg[NV];
-    int64_t src[NV];
+    float4 xh[NV], gg[NV], dv[NV];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
+    for (int k = 0; k < NV; ++k) { xh[k] = ldb4(rx, xoff[k]); dv[k] = ldb4(rdy, (lane + 64 * k) * 16); }
+#pragma unroll
     for (int k = 0; k < NV; ++k) {
-      const int j = lane + 64 * k;
-      if (j < g.C) {
-        src[k] = pm_src(g, row, j);
-        const float4 xv = x[src[k]], d = dy[row * g.C + j], gm = gamma[j];
-        xh[k] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
-        gg[k] = make_float4(d.x * gm.x, d.y * gm.y, d.z * gm.z, d.w * gm.w);
-        s1 += (gg[k].x + gg[k].y) + (gg[k].z + gg[k].w);
-        s2 += (gg[k].x * xh[k].x + gg[k].y * xh[k].y) + (gg[k].z * xh[k].z + gg[k].w * xh[k].w);
-        ag[k].x = fmaf(d.x, xh[k].x, ag[k].x); ag[k].y = fmaf(d.y, xh[k].y, ag[k].y);
-        ag[k].z = fmaf(d.z, xh[k].z, ag[k].z); ag[k].w = fmaf(d.w, xh[k].w, ag[k].w);
-        ab[k].x += d.x; ab[k].y += d.y; ab[k].z += d.z; ab[k].w += d.w;
-      } else {
-        src[k] = 0; xh[k] = make_float4(0.f, 0.f, 0.f, 0.f); gg[k] = xh[k];
-      }
+      const bool in = lane + 64 * k < g.C;
+      const float4 xv = xh[k], d = dv[k];                            // d = 0 beyond the row: every product below vanishes
+      xh[k] = in ? make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd)
+                 : make_float4(0.f, 0.f, 0.f, 0.f);
+      gg[k] = make_float4(d.x * gm[k].x, d.y * gm[k].y, d.z * gm[k].z, d.w * gm[k].w);
+      s1 += (gg[k].x + gg[k].y) + (gg[k].z + gg[k].w);
+      s2 += (gg[k].x * xh[k].x + gg[k].y * xh[k].y) + (gg[k].z * xh[k].z + gg[k].w * xh[k].w);
+      ag[k].x = fmaf(d.x, xh[k].x, ag[k].x); ag[k].y = fmaf(d.y, xh[k].y, ag[k].y);
+      ag[k].z = fmaf(d.z, xh[k].z, ag[k].z); ag[k].w = fmaf(d.w, xh[k].w, ag[k].w);
+      ab[k].x += d.x; ab[k].y += d.y; ab[k].z += d.z; ab[k].w += d.w;
     }
     const float m1 = wave_sum(s1) * inv_n, m2 = wave_sum(s2) * inv_n;
 #pragma unroll
-    for (int k = 0; k < NV; ++k) {
-      if (lane + 64 * k < g.C)
-        dinp[src[k]] = make_float4(rstd * (gg[k].x - m1 - xh[k].x * m2), rstd * (gg[k].y - m1 - xh[k].y * m2),
-                                   rstd * (gg[k].z - m1 - xh[k].z * m2), rstd * (gg[k].w - m1 - xh[k].w * m2));
-    }
+    for (int k = 0; k < NV; ++k)
+      stb4(rdx, xoff[k], make_float4(rstd * (gg[k].x - m1 - xh[k].x * m2), rstd * (gg[k].y - m1 - xh[k].y * m2),
+                                     rstd * (gg[k].z - m1 - xh[k].z * m2), rstd * (gg[k].w - m1 - xh[k].w * m2)));
   }
   float4* wrow = ws + wave_global * 2 * g.C;
 #pragma unroll
@@ -140,7 +166,7 @@ __global__ __launch_bounds__(256) void nchw_ln_rows_fwd_kernel(const float* __re
                                                                float* __restrict__ mu_out, float* __restrict__ rstd_out, int C,
                                                                int HW, int tiles_per_img, int64_t ntiles) {
   extern __shared__ float pe_tile[];            // [C][kPeS]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const float inv_n = 1.f / C;
   float gm[NV], bt[NV];
 #pragma unroll
@@ -153,11 +179,20 @@ __global__ __launch_bounds__(256) void nchw_ln_rows_fwd_kernel(const float* __re
     const int64_t b = tile / tiles_per_img;
     const int p0 = (int)(tile - b * tiles_per_img) * kPeT;
     const int np = min(kPeT, HW - p0);
-    const float* xb = x + b * (int64_t)C * HW + p0;
+    const rsrc_t rt = make_rsrc(x + b * (int64_t)C * HW + p0, ((int64_t)(C - 1) * HW + np) * 4);     // this tile's C rows of np positions
     __syncthreads();                            // the previous tile's readers are done
-    for (int idx = tid; idx < C * kPeT; idx += 256) {
-      const int c = idx / kPeT, pp = idx % kPeT;
-      pe_tile[c * kPeS + pp] = pp < np ? xb[(int64_t)c * HW + pp] : 0.f;
+    for (int idx0 = tid; idx0 < C * kPeT; idx0 += 4 * 256) {       // four loads of a thread in flight together, no branch around them
+      float t[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int idx = idx0 + u * 256, c = idx / kPeT, pp = idx % kPeT;
+        t[u] = ldb1(rt, (idx < C * kPeT && pp < np) ? (c * HW + pp) * 4 : kOOB);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int idx = idx0 + u * 256;
+        if (idx < C * kPeT) pe_tile[(idx / kPeT) * kPeS + idx % kPeT] = t[u];
+      }
     }
     __syncthreads();
     for (int pp = wave; pp < np; pp += 4) {
@@ -197,7 +232,7 @@ __global__ __launch_bounds__(256) void nchw_ln_rows_bwd_kernel(const float* __re
                                                                float* __restrict__ ws, int C, int HW, int tiles_per_img,
                                                                int64_t ntiles) {
   extern __shared__ float pe_tile[];            // [C][kPeS], then [4][2C] for the final reduction
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const float inv_n = 1.f / C;
   float gm[NV], ag[NV], ab[NV];
 #pragma unroll
@@ -211,22 +246,35 @@ __global__ __launch_bounds__(256) void nchw_ln_rows_bwd_kernel(const float* __re
     const int p0 = (int)(tile - b * tiles_per_img) * kPeT;
     const int np = min(kPeT, HW - p0);
     const int64_t base = b * (int64_t)C * HW + p0;
+    const rsrc_t rt = make_rsrc(x + base, ((int64_t)(C - 1) * HW + np) * 4);
     __syncthreads();
-    for (int idx = tid; idx < C * kPeT; idx += 256) {
-      const int c = idx / kPeT, pp = idx % kPeT;
-      pe_tile[c * kPeS + pp] = pp < np ? x[base + (int64_t)c * HW + pp] : 0.f;
+    for (int idx0 = tid; idx0 < C * kPeT; idx0 += 4 * 256) {
+      float t[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int idx = idx0 + u * 256, c = idx / kPeT, pp = idx % kPeT;
+        t[u] = ldb1(rt, (idx < C * kPeT && pp < np) ? (c * HW + pp) * 4 : kOOB);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int idx = idx0 + u * 256;
+        if (idx < C * kPeT) pe_tile[(idx / kPeT) * kPeS + idx % kPeT] = t[u];
+      }
     }
     __syncthreads();
     for (int pp = wave; pp < np; pp += 4) {
       const int64_t row = b * HW + p0 + pp;
       const float mean = mu_in[row], rstd = rstd_in[row];
-      float xh[NV], gg[NV];
+      const rsrc_t rdy = make_rsrc(dy + row * C, (int64_t)C * 4);
+      float xh[NV], gg[NV], dv[NV];
       float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int k = 0; k < NV; ++k) dv[k] = ldb1(rdy, (lane + 64 * k) * 4);
 #pragma unroll
       for (int k = 0; k < NV; ++k) {
         const int c = lane + 64 * k;
         if (c < C) {
-          const float d = dy[row * C + c];
+          const float d = dv[k];
           xh[k] = (pe_tile[c * kPeS + pp] - mean) * rstd;
           gg[k] = d * gm[k];
           s1 += gg[k];
@@ -263,9 +311,9 @@ __global__ __launch_bounds__(256) void nchw_ln_rows_bwd_kernel(const float* __re
 
 inline int pe_grid(int64_t ntiles) { return (int)(ntiles < 1 ? 1 : (ntiles > 2048 ? 2048 : ntiles)); }
 
-inline int pm_grid(int64_t nrows) {   // >= 4 rows per wavefront, at most 256 workgroups (= 1024 partial dgamma/dbeta rows)
-  int64_t b = (nrows + 15) / 16;
-  return (int)(b < 1 ? 1 : (b > 256 ? 256 : b));
+inline int pm_grid(int64_t nrows) {   // >= 4 rows per wavefront, at most 1024 workgroups: 16 wavefronts per CU (4 per CU left the loads
+  int64_t b = (nrows + 15) / 16;      // of a wavefront's row as the only ones in flight), 4096 partial dgamma / dbeta rows at most
+  return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b));
 }
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 }  // namespace
