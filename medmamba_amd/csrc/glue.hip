@@ -1678,6 +1678,14 @@ __device__ __forceinline__ void pack_extra_blocks(const PackExtra& ex, int D, fl
     if (col < 2 * D) {
       const float* src = ex.ln_ws + col;
       int r = rl;
+      // eight loads in flight, added in the order of the two-row loop below (same bits): with two in flight the 112-784 rows of a
+      // lane were 56-392 dependent round trips to L2
+      for (; r + 7 * RL < ex.ln_rows; r += 8 * RL) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = src[(int64_t)(r + u * RL) * 2 * D];
+        a0 += v[0]; a1 += v[1]; a0 += v[2]; a1 += v[3]; a0 += v[4]; a1 += v[5]; a0 += v[6]; a1 += v[7];
+      }
       for (; r + RL < ex.ln_rows; r += 2 * RL) { a0 += src[(int64_t)r * 2 * D]; a1 += src[(int64_t)(r + RL) * 2 * D]; }
       if (r < ex.ln_rows) a0 += src[(int64_t)r * 2 * D];
     }
@@ -1702,6 +1710,12 @@ __device__ __forceinline__ void pack_extra_blocks(const PackExtra& ex, int D, fl
       for (int s = 0; s < ex.dw_S; ++s) {
         const float* src = ex.dw_ws + ((int64_t)d * ex.dw_S + s) * 10 + j;
         int q = q0;
+        for (; q + 7 < q1; q += 8) {                   // eight loads in flight, added in the order of the four-wide loop below
+          float v[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) v[u] = src[(q + u) * bstride];
+          a0 += v[0]; a1 += v[1]; a2 += v[2]; a3 += v[3]; a0 += v[4]; a1 += v[5]; a2 += v[6]; a3 += v[7];
+        }
         for (; q + 3 < q1; q += 4) {
           a0 += src[q * bstride]; a1 += src[(q + 1) * bstride]; a2 += src[(q + 2) * bstride]; a3 += src[(q + 3) * bstride];
         }
@@ -1759,6 +1773,13 @@ __global__ __launch_bounds__(256) void ss2d_pack_kernel(const float* __restrict_
       const float* src = s2 + (i - o2);
       float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
       int q = 0;
+      for (; q + 16 <= nparts; q += 16) {                // sixteen loads in flight, added in the order of the four-wide loop below
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = src[(int64_t)(q + u) * S];
+#pragma unroll
+        for (int u = 0; u < 16; u += 4) { a0 += v[u]; a1 += v[u + 1]; a2 += v[u + 2]; a3 += v[u + 3]; }
+      }
       for (; q + 4 <= nparts; q += 4) {
         a0 += src[(int64_t)q * S]; a1 += src[(int64_t)(q + 1) * S]; a2 += src[(int64_t)(q + 2) * S]; a3 += src[(int64_t)(q + 3) * S];
       }
