@@ -4,7 +4,7 @@
 // per-image partial products of the deterministic conv weight gradient — ~50 ATen reductions of 1-3 MB per training step, each a
 // 10 us launch of a generic reduce kernel.  Here: SX inner slots (float4 each) x 256/SX interleaved lead parts per 256-thread
 // workgroup, 8 loads in flight per thread, the partial sums joined through LDS in a fixed order (deterministic, no atomics).  Meant
-// for lead dimensions of a batch (<= a few hundred rows): the callers leave taller reductions (thousands of partial rows) to ATen.
+// for lead dimensions of a batch or of the partial rows of a kernel (<= 4096 rows: the callers leave taller reductions to ATen).
 #include "mm_common.h"
 #include "medmamba_hip.h"
 
@@ -67,8 +67,10 @@ extern "C" int mm_sum_lead(const float* src, float* dst, int nlead, int64_t ninn
   if (nlead <= 0 || ninner <= 0 || lead_stride < ninner) return MM_ERR_SHAPE;
   const bool vec = ninner % 4 == 0 && lead_stride % 4 == 0 && ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0;
   const int64_t slots = vec ? ninner / 4 : ninner;
-  int sx_log2 = 6;                                      // 64 slots per workgroup; narrow tensors: fewer slots, more lead parts
+  int sx_log2 = 6;                                      // 64 slots per workgroup; narrow tensors: fewer slots, more lead parts;
   while (sx_log2 > 3 && (int64_t)(1 << (sx_log2 - 1)) >= slots) --sx_log2;
+  // tall tensors (partial rows of a thousand workgroups): at most 32 rows per part = four rounds of eight loads, whatever the width
+  while (sx_log2 > 3 && nlead > (256 >> sx_log2) * 32) --sx_log2;
   const int64_t nb = (slots + (1 << sx_log2) - 1) >> sx_log2;
   if (nb > 0x7fffffffll) return MM_ERR_SHAPE;
   if (vec) hipLaunchKernelGGL(sum_lead_kernel<true>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, src, dst, nlead, ninner, lead_stride, sx_log2);

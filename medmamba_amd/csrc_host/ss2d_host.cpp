@@ -106,7 +106,7 @@ inline void gemm_out(Tensor& out, const Tensor& a, const Tensor& b, void* stream
 // same bits); `out` (optional) must be dense with the shape of t[0]
 inline Tensor sum_lead(const Tensor& t, void* stream, const Tensor& out_ = Tensor()) {
   const int64_t n = t.dim() >= 1 ? t.size(0) : 0;
-  if (t.dim() >= 2 && n >= 2 && n <= 256 && t.is_contiguous() && t.numel() > 0 && (!out_.defined() || (out_.is_contiguous() && out_.numel() * n == t.numel()))) {
+  if (t.dim() >= 2 && n >= 2 && n <= 4096 && t.is_contiguous() && t.numel() > 0 && (!out_.defined() || (out_.is_contiguous() && out_.numel() * n == t.numel()))) {
     Tensor out = out_.defined() ? out_ : at::empty(t.sizes().slice(1), t.options());
     const int64_t ninner = t.numel() / n;
     check(mm_sum_lead(fp(t), fpm(out), (int)n, ninner, ninner, stream), "mm_sum_lead");

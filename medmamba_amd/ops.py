@@ -61,7 +61,7 @@ def sum_lead(t, out=None):
     mm_sum_lead for dense fp32 HIP tensors (one small launch with a fixed summation order instead of ATen's generic 10-us
     reduction; csrc_host sum_lead is the same call, so both launch routes give the same bits); anything else through torch."""
     n = t.shape[0] if t.dim() >= 1 else 0
-    if (t.is_cuda and t.dtype == torch.float32 and t.dim() >= 2 and 2 <= n <= 256 and t.is_contiguous() and t.numel() > 0
+    if (t.is_cuda and t.dtype == torch.float32 and t.dim() >= 2 and 2 <= n <= 4096 and t.is_contiguous() and t.numel() > 0
             and (out is None or (out.is_contiguous() and out.dtype == torch.float32 and out.numel() * n == t.numel()))):
         if out is None:
             out = torch.empty(t.shape[1:], device=t.device, dtype=torch.float32)

@@ -640,7 +640,7 @@ def test_im2col3x3_is_unfold(shape):
     assert _lib.lib().mm_im2col3x3(x.data_ptr(), cols.data_ptr(), B, C, H, W, 0, None) == -2
 
 
-@pytest.mark.parametrize("shape", [(64, 4, 35, 96), (2, 7), (3, 1), (64, 768, 384), (5, 13), (17, 2, 48, 48), (130, 10), (1, 8), (300, 8), (256, 2 * 96), (200, 1536), (33, 4, 3)])
+@pytest.mark.parametrize("shape", [(64, 4, 35, 96), (2, 7), (3, 1), (64, 768, 384), (5, 13), (17, 2, 48, 48), (130, 10), (1, 8), (300, 8), (256, 2 * 96), (200, 1536), (33, 4, 3), (1024, 96), (4096, 768), (3136, 6), (5000, 16)])
 def test_sum_lead_matches_torch_sum_and_is_reproducible(shape):
     """mm_sum_lead (ops.sum_lead / csrc_host sum_lead): t.sum(0) of dense fp32 tensors — the batch sums behind the batched
     weight-gradient GEMMs and the partial rows — vector and scalar form, into a fresh tensor and into a given one."""
