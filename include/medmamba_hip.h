@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MM_ABI_VERSION 21
+#define MM_ABI_VERSION 22
 
 enum mm_status {
   MM_OK = 0,
@@ -366,6 +366,11 @@ int mm_channel_sum_nchw(const float* x, float* out, int batch, int C, int HW, vo
  * the lead dimension — by the width of the tensor —, each summed in order, then joined in order) — the sum over the batch behind the batched weight-gradient
  * GEMMs of MedMamba.py:259, 262, 292, 302 in batch-major storage and behind per-workgroup partial rows (since ABI 21). */
 int mm_sum_lead(const float* src, float* dst, int nlead, int64_t ninner, int64_t lead_stride, void* stream);
+/* The same sum of a dense (nlead, nchunks, chunk) source into a destination whose chunks are `dst_chunk_stride` floats apart
+ * (dst[c * dst_chunk_stride + o] = sum_j src[j][c][o]; the same bits as mm_sum_lead on a dense destination): the per-workgroup
+ * partial dB / dC planes of mm_scan_bwd (mm_scan_args.dBC_sc) summed straight into the B / C rows of d(x_dbl), which sit between
+ * the dt rows of the next direction (since ABI 22). */
+int mm_sum_lead_chunks(const float* src, float* dst, int nlead, int64_t nchunks, int64_t chunk, int64_t dst_chunk_stride, void* stream);
 
 /* fp32 GEMMs of the projections around the scan (MedMamba.py:259, 262, 292, 302; the conv branch's 1x1 conv :345) without the
  * host-side cost of a framework dispatch (measured: 7.6 us per call against 17-31 us through torch.bmm on this image).  The

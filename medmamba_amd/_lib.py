@@ -14,7 +14,7 @@ SO_PATH = os.path.join(_HERE, "lib", "libmedmamba_hip.so")
 if os.environ.get("MM_HIP_LIB"):
     SO_PATH = os.path.abspath(os.environ["MM_HIP_LIB"])
 
-ABI_VERSION = 21        # == MM_ABI_VERSION of include/medmamba_hip.h (checked when the library is loaded)
+ABI_VERSION = 22        # == MM_ABI_VERSION of include/medmamba_hip.h (checked when the library is loaded)
 _f32p = ctypes.c_void_p
 _i64 = ctypes.c_int64
 
@@ -93,6 +93,7 @@ SYMBOLS = {
     "mm_channel_sum_nchw_split": (ctypes.c_int, [ctypes.c_int] * 2),
     "mm_channel_sum_nchw": (ctypes.c_int, [_f32p, _f32p] + [ctypes.c_int] * 3 + [ctypes.c_void_p]),
     "mm_sum_lead": (ctypes.c_int, [_f32p, _f32p, ctypes.c_int, _i64, _i64, ctypes.c_void_p]),
+    "mm_sum_lead_chunks": (ctypes.c_int, [_f32p, _f32p, ctypes.c_int, _i64, _i64, _i64, ctypes.c_void_p]),
     "mm_ss2d_pack_size": (ctypes.c_int, [ctypes.c_int] * 4),
     "mm_ss2d_pack_fwd": (ctypes.c_int, [_f32p] * 6 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
     "mm_ss2d_pack_bwd": (ctypes.c_int, [_f32p] * 4 + [ctypes.c_int] * 5 + [_f32p, ctypes.c_int, _f32p, _f32p, ctypes.c_int, ctypes.c_int,

@@ -13,7 +13,7 @@ using namespace mm;
 
 template <bool VEC>
 __global__ __launch_bounds__(256) void sum_lead_kernel(const float* __restrict__ src, float* __restrict__ dst, int nlead, int64_t ninner,
-                                                       int64_t lead_stride, int sx_log2) {
+                                                       int64_t lead_stride, int sx_log2, int64_t chunk, int64_t dst_chunk_stride) {
   constexpr int W = VEC ? 4 : 1;                       // floats per thread
   __shared__ float part[256][W];
   // 256 threads = SX inner slots x PY lead parts (SX = 64 for wide tensors, fewer slots -> more parts for narrow ones); part p
@@ -56,16 +56,21 @@ __global__ __launch_bounds__(256) void sum_lead_kernel(const float* __restrict__
     for (int w = 0; w < W; ++w) {
       float s = part[col][w];
       for (int q = 1; q < PY; ++q) s += part[q * SX + col][w];
-      if (i0 + w < ninner) dst[i0 + w] = s;
+      // chunked destination (mm_sum_lead_chunks): element i of the dense source row lies at (i / chunk) * stride + i % chunk
+      if (i0 + w < ninner) dst[chunk > 0 ? ((i0 + w) / chunk) * dst_chunk_stride + (i0 + w) % chunk : i0 + w] = s;
     }
   }
 }
 }  // namespace
 
-extern "C" int mm_sum_lead(const float* src, float* dst, int nlead, int64_t ninner, int64_t lead_stride, void* stream) {
+namespace {
+int sum_lead_launch(const float* src, float* dst, int nlead, int64_t ninner, int64_t lead_stride, int64_t chunk, int64_t dst_chunk_stride,
+                    void* stream) {
   if (!src || !dst) return MM_ERR_NULL;
   if (nlead <= 0 || ninner <= 0 || lead_stride < ninner) return MM_ERR_SHAPE;
-  const bool vec = ninner % 4 == 0 && lead_stride % 4 == 0 && ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0;
+  if (chunk > 0 && (ninner % chunk != 0 || dst_chunk_stride < chunk)) return MM_ERR_SHAPE;
+  const bool vec = ninner % 4 == 0 && lead_stride % 4 == 0 && ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0 &&
+                   (chunk <= 0 || (chunk % 4 == 0 && dst_chunk_stride % 4 == 0));
   const int64_t slots = vec ? ninner / 4 : ninner;
   int sx_log2 = 6;                                      // 64 slots per workgroup; narrow tensors: fewer slots, more lead parts;
   while (sx_log2 > 3 && (int64_t)(1 << (sx_log2 - 1)) >= slots) --sx_log2;
@@ -73,7 +78,18 @@ extern "C" int mm_sum_lead(const float* src, float* dst, int nlead, int64_t ninn
   while (sx_log2 > 3 && nlead > (256 >> sx_log2) * 32) --sx_log2;
   const int64_t nb = (slots + (1 << sx_log2) - 1) >> sx_log2;
   if (nb > 0x7fffffffll) return MM_ERR_SHAPE;
-  if (vec) hipLaunchKernelGGL(sum_lead_kernel<true>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, src, dst, nlead, ninner, lead_stride, sx_log2);
-  else hipLaunchKernelGGL(sum_lead_kernel<false>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, src, dst, nlead, ninner, lead_stride, sx_log2);
+  if (vec) hipLaunchKernelGGL(sum_lead_kernel<true>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, src, dst, nlead, ninner, lead_stride, sx_log2, chunk, dst_chunk_stride);
+  else hipLaunchKernelGGL(sum_lead_kernel<false>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, src, dst, nlead, ninner, lead_stride, sx_log2, chunk, dst_chunk_stride);
   return (int)hipGetLastError();
+}
+}  // namespace
+
+extern "C" int mm_sum_lead(const float* src, float* dst, int nlead, int64_t ninner, int64_t lead_stride, void* stream) {
+  return sum_lead_launch(src, dst, nlead, ninner, lead_stride, 0, 0, stream);
+}
+
+extern "C" int mm_sum_lead_chunks(const float* src, float* dst, int nlead, int64_t nchunks, int64_t chunk, int64_t dst_chunk_stride,
+                                  void* stream) {
+  if (nchunks <= 0 || chunk <= 0) return MM_ERR_SHAPE;
+  return sum_lead_launch(src, dst, nlead, nchunks * chunk, nchunks * chunk, chunk, dst_chunk_stride, stream);
 }

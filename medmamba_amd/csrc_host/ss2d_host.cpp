@@ -167,6 +167,34 @@ inline Tensor like_strided(const Tensor& dst, int64_t lead) {
   return at::empty(shape, dst.options()).permute(perm);
 }
 
+// dst = planes.sum(0) for the dense planes of like_strided(dst, W): through mm_sum_lead_chunks when the view `dst` is a sequence of
+// dense chunks a constant stride apart (selective_scan_interface._chunks_of: the same test, the same call), else ATen
+inline void sum_planes(Tensor& dst, const Tensor& planes, void* stream) {
+  std::vector<std::pair<int64_t, int64_t>> dims;                 // (stride, size), outermost first
+  for (int64_t i = 0; i < dst.dim(); ++i)
+    if (dst.size(i) > 1) dims.emplace_back(dst.stride(i), dst.size(i));
+  std::sort(dims.begin(), dims.end(), [](const auto& a, const auto& b) { return a.first > b.first; });
+  int64_t chunk = 1;
+  size_t i = dims.size();
+  while (i > 0 && dims[i - 1].first == chunk) { chunk *= dims[i - 1].second; --i; }
+  int64_t stride = chunk, n = 1;
+  bool ok = true;
+  if (i > 0) {
+    stride = dims[i - 1].first;
+    for (size_t j = i; j-- > 0;) {
+      if (dims[j].first != stride * n) { ok = false; break; }
+      n *= dims[j].second;
+    }
+    ok = ok && stride >= chunk;
+  }
+  const int64_t W = planes.size(0);
+  if (ok && W >= 2 && W <= 4096) {
+    check(mm_sum_lead_chunks(fp(planes), fpm(dst), (int)W, n, chunk, stride, stream), "mm_sum_lead_chunks");
+  } else {
+    at::sum_out(dst, planes, DIM0);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // forward.  Returns {out (B, d_model, L), xz, u2, x_dbl, delta, P, x_chk, m, mu, rstd, y}
 // ---------------------------------------------------------------------------------------------------------------------
@@ -350,7 +378,7 @@ std::vector<Tensor> ss2d_bwd(const Tensor& dout_, const Tensor& x, const Tensor&
     if (ev0) check(mm_event_record(reinterpret_cast<void*>(ev0), stream), "mm_event_record");
     check(mm_scan_bwd(&a, stream), "mm_scan_bwd");
     if (ev1) check(mm_event_record(reinterpret_cast<void*>(ev1), stream), "mm_event_record");
-    if (pl.defined()) at::sum_out(dBC, pl, DIM0);
+    if (pl.defined()) sum_planes(dBC, pl, stream);
   }
   Tensor du2;
   if (cm) {

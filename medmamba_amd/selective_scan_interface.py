@@ -164,6 +164,23 @@ def _launch_fwd(u, delta, A, B, C, D, delta_bias, delta_softplus, want_chk, vari
     return out, x_chk
 
 
+def _chunks_of(t):
+    """(nchunks, chunk, chunk_stride) if the view `t` is a sequence of dense chunks a constant stride apart (the B / C rows of
+    d(x_dbl): 32 rows of every direction, the dt rows in between), else None."""
+    dims = sorted(((st, sz) for st, sz in zip(t.stride(), t.shape) if sz > 1), reverse=True)
+    chunk, i = 1, len(dims)
+    while i > 0 and dims[i - 1][0] == chunk:
+        chunk *= dims[i - 1][1]; i -= 1
+    if i == 0:
+        return (1, chunk, chunk)
+    stride, n = dims[i - 1][0], 1
+    for j in range(i - 1, -1, -1):                  # the outer dimensions must flatten to one index with that stride
+        if dims[j][0] != stride * n:
+            return None
+        n *= dims[j][1]
+    return (n, chunk, stride) if stride >= chunk else None
+
+
 def _like_strided(dst, lead):
     """Uninitialised fp32 (lead, *dst.shape) whose planes have the same dimension order in memory as the view `dst` (dense)."""
     order = sorted(range(dst.dim()), key=lambda d: (-dst.stride(d), d))
@@ -241,7 +258,13 @@ def _launch_bwd(u, delta, A, B, C, D, delta_bias, x_chk, dout, delta_softplus, s
         KERNEL_TIMER.stop("scan_bwd", t0, scan_bytes_bwd(batch, dim, L, N, G), batch * dim * L * N)
     _lib.check(rc, "mm_scan_bwd")
     if planes is not None:
-        torch.sum(planes, dim=0, out=dBC_dst)
+        ch = _chunks_of(dBC_dst)
+        if ch is not None and 2 <= W <= 4096:      # mm_sum_lead_chunks: the planes are dense in dBC_dst's own dimension order
+            with _lib.device_guard(dev):
+                _lib.check(lib.mm_sum_lead_chunks(planes.data_ptr(), dBC_dst.data_ptr(), W, ch[0], ch[1], ch[2], _lib.raw_stream()),
+                           "mm_sum_lead_chunks")
+        else:
+            torch.sum(planes, dim=0, out=dBC_dst)
     dA = dD = dbias = None
     if own_parts:
         sums = pbuf.sum(0)

@@ -640,6 +640,36 @@ def test_im2col3x3_is_unfold(shape):
     assert _lib.lib().mm_im2col3x3(x.data_ptr(), cols.data_ptr(), B, C, H, W, 0, None) == -2
 
 
+@pytest.mark.parametrize("cm", [False, True])
+def test_sum_lead_chunks_fills_the_bc_rows_of_dx_dbl(cm):
+    """mm_sum_lead_chunks: the per-workgroup partial dB / dC planes of the backward scan summed straight into rows R.. of every
+    direction of d(x_dbl) (batch-major: (B, 4, C, L); channel-major: (4, C, B*L)) — same bits as mm_sum_lead on a dense copy, the dt
+    rows in between untouched."""
+    from medmamba_amd import _lib, selective_scan_interface as ssi
+    B, C, L, R, W = 5, 44, 196, 12, 6
+    g = torch.Generator(device=DEV).manual_seed(3)
+    if cm:
+        dx_dbl = torch.full((4, C, B * L), 7.0, device=DEV)
+        dst = dx_dbl.view(4, C, B, L).permute(2, 0, 1, 3)[:, :, R:]
+    else:
+        dx_dbl = torch.full((B, 4, C, L), 7.0, device=DEV)
+        dst = dx_dbl[:, :, R:]
+    planes = ssi._like_strided(dst, W)
+    planes.copy_(torch.randn(W, *dst.shape, device=DEV, generator=g))
+    ch = ssi._chunks_of(dst)
+    assert ch == ((4, 32 * B * L, C * B * L) if cm else (B * 4, 32 * L, C * L))
+    _lib.check(_lib.lib().mm_sum_lead_chunks(planes.data_ptr(), dst.data_ptr(), W, ch[0], ch[1], ch[2], _lib.raw_stream()), "mm_sum_lead_chunks")
+    from medmamba_amd import ops
+    dense = ops.sum_lead(planes.permute(0, *[i + 1 for i in sorted(range(dst.dim()), key=lambda i: -dst.stride(i))]).contiguous())
+    want = planes.double().sum(0)
+    assert float((dst.double() - want).abs().max()) <= 1e-5 * float(want.abs().max())
+    order = sorted(range(dst.dim()), key=lambda i: -dst.stride(i))
+    assert torch.equal(dst.permute(*order).contiguous(), dense)                # the same bits as the dense sum
+    rest = dx_dbl.view(4, C, B, L)[:, :R] if cm else dx_dbl[:, :, :R]
+    assert bool((rest == 7.0).all())                                           # the dt rows are not written
+    assert _lib.lib().mm_sum_lead_chunks(planes.data_ptr(), dst.data_ptr(), W, 0, 8, 8, None) == -2
+
+
 @pytest.mark.parametrize("shape", [(64, 4, 35, 96), (2, 7), (3, 1), (64, 768, 384), (5, 13), (17, 2, 48, 48), (130, 10), (1, 8), (300, 8), (256, 2 * 96), (200, 1536), (33, 4, 3), (1024, 96), (4096, 768), (3136, 6), (5000, 16)])
 def test_sum_lead_matches_torch_sum_and_is_reproducible(shape):
     """mm_sum_lead (ops.sum_lead / csrc_host sum_lead): t.sum(0) of dense fp32 tensors — the batch sums behind the batched
