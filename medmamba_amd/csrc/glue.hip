@@ -23,6 +23,14 @@ __device__ __forceinline__ void wave_lds_sync() {
 
 using namespace mm;
 
+// bounds-checked dword access through a buffer descriptor (an offset of kOOB reads 0 / drops the store): see the depthwise kernels
+__device__ __forceinline__ float ldb(rsrc_t r, int off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+}
+__device__ __forceinline__ void stb(rsrc_t r, int off, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, off, 0, 0);
+}
+
 // grid: (ceil(P/32), ceil(C2/32), B); block 256 = 8 rows x 32 lanes
 template <bool SSM_CF>
 __global__ __launch_bounds__(256) void shuffle_residual_fwd_kernel(const float* __restrict__ left, const float* __restrict__ ssm,
@@ -152,12 +160,6 @@ struct DivMod {
 // SLOWER, 44.1 -> 53.2 us at 14x14 — many small waves already keep enough loads in flight there.  Nor are they load-bound at all:
 // one b128 load per lane and operand plane (a 14x14 plane is 49 float4), parked in LDS in memory order, moved the fused backward
 // 41.8 -> 41.2 us and the forward 22.1 -> 21.6 us — ~520 VALU / LDS instructions per plane and wave are what these kernels cost.)
-__device__ __forceinline__ float ldb(rsrc_t r, int off) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
-}
-__device__ __forceinline__ void stb(rsrc_t r, int off, float v) {
-  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, off, 0, 0);
-}
 constexpr int kDwU = 4;      // elements per thread and chunk
 
 // ---- depthwise 3x3 conv + bias + SiLU (MedMamba.py:153-162, 295), writing the scan's two input orders --------
@@ -550,19 +552,26 @@ __global__ __launch_bounds__(256) void cross_merge_fwd_kernel(const float* __res
   const float* o1 = o0 + (int64_t)D * L;
   const float* o2 = o1 + (int64_t)D * L;
   const float* o3 = o2 + (int64_t)D * L;
+  // one descriptor per plane, no branch around a load: the 16 loads of a thread are in flight together (§4.4)
+  const rsrc_t r0 = make_rsrc(o0, L * 4), r1 = make_rsrc(o1, L * 4), r2 = make_rsrc(o2, L * 4), r3 = make_rsrc(o3, L * 4);
+  float c2[4], c3[4], a0[4], a1[4];
 #pragma unroll
-  for (int r = ty; r < 32; r += 8) {         // rows w0+r of the column-major planes, lanes along h
-    const int w = w0 + r, h = h0 + tx;
-    tile[r][tx] = (w < W && h < H) ? o2[(int64_t)w * H + h] + o3[(int64_t)w * H + h] : 0.f;
+  for (int q = 0; q < 4; ++q) {
+    const int r = ty + 8 * q;
+    const int wc = w0 + r, hc = h0 + tx;     // rows w0+r of the column-major planes, lanes along h
+    const int oc = (wc < W && hc < H) ? (wc * H + hc) * 4 : kOOB;
+    c2[q] = ldb(r2, oc); c3[q] = ldb(r3, oc);
+    const int hr = h0 + r, wr = w0 + tx;     // rows h0+r of the row-major planes, lanes along w
+    const int orow = (hr < H && wr < W) ? (hr * W + wr) * 4 : kOOB;
+    a0[q] = ldb(r0, orow); a1[q] = ldb(r1, orow);
   }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) tile[ty + 8 * q][tx] = c2[q] + c3[q];
   __syncthreads();
 #pragma unroll
-  for (int r = ty; r < 32; r += 8) {         // rows h0+r of the row-major planes, lanes along w
-    const int h = h0 + r, w = w0 + tx;
-    if (h < H && w < W) {
-      const int64_t i = (int64_t)h * W + w;
-      m[b * m_sb + d * m_sd + i] = o0[i] + o1[i] + tile[tx][r];
-    }
+  for (int q = 0; q < 4; ++q) {
+    const int r = ty + 8 * q, h = h0 + r, w = w0 + tx;
+    if (h < H && w < W) m[b * m_sb + d * m_sd + (int64_t)h * W + w] = a0[q] + a1[q] + tile[tx][r];
   }
 }
 
@@ -577,11 +586,15 @@ __global__ __launch_bounds__(256) void plane_transpose_kernel(const float* __res
   const int b = pl / D, d = pl % D;
   const float* s = src + (int64_t)b * src_sb + (int64_t)d * src_sd;
   float* t = dst + (int64_t)b * dst_sb + (int64_t)d * dst_sd;
+  const rsrc_t rs = make_rsrc(s, (int64_t)H * W * 4);
+  float v[4];
 #pragma unroll
-  for (int r = ty; r < 32; r += 8) {
-    const int h = h0 + r, w = w0 + tx;
-    tile[r][tx] = (h < H && w < W) ? s[(int64_t)h * W + w] : 0.f;
+  for (int q = 0; q < 4; ++q) {
+    const int h = h0 + ty + 8 * q, w = w0 + tx;
+    v[q] = ldb(rs, (h < H && w < W) ? (h * W + w) * 4 : kOOB);
   }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) tile[ty + 8 * q][tx] = v[q];
   __syncthreads();
 #pragma unroll
   for (int r = ty; r < 32; r += 8) {
