@@ -93,6 +93,7 @@ def _need_hip(*ts):
 #                per block 714 -> 458 us at L=196 and 582 -> 342 us at L=49, but 1086 -> 1880 us at L=3136 (hipBLASLt has no
 #                good split-K for K = B*L ~ 2e5), hence channel-major only for short sequences.
 # Every plane kernel takes (batch stride, channel stride), so both layouts run the same code.
+_CM_MAX_L = int(os.environ.get("MM_CM_MAX_L", "256"))   # longest sequence stored channel-major (tuning knob)
 _LAYOUT = os.environ.get("MM_LAYOUT", "auto")          # "auto" | "bm" | "cm" (tests force both)
 _PACK_FOLD = os.environ.get("MM_PACK_FOLD", "1") == "1"  # the SS2D backward's small reductions ride on mm_ss2d_pack_bwd (0: ATen sums)
 _FUSE_DT = os.environ.get("MM_FUSE_DT", "1") == "1"     # inference: dt projection inside the scan kernel (MM_FUSE_DT=0: always a GEMM)
@@ -103,7 +104,7 @@ def channel_major(B, L):
         return True
     if _LAYOUT == "bm":
         return False
-    return B > 1 and L <= 256 and B * L <= 65536       # beyond that K = B*L makes the weight-gradient GEMMs split-K bound
+    return B > 1 and L <= _CM_MAX_L and B * L <= 65536  # beyond that K = B*L makes the weight-gradient GEMMs split-K bound
 
 
 def _planes(B, D, L, device, cm):
