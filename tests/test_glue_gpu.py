@@ -370,6 +370,19 @@ def test_ln_gate_kernels_all_plans(shape, cm):
     assert close(s[:D], gr.grad, 1e-4) and close(s[D:], br.grad, 1e-4)
 
 
+def test_ln_gate_refuses_channel_strides_beyond_its_32_bit_offsets():
+    """The register-resident LayerNorm + gate kernels address one step of channel rows with 32-bit byte offsets from a descriptor
+    that starts at the step (glue.hip rows_rsrc): a channel stride of 2^26 floats (16 rows x 256 MB) no longer fits and the entry
+    points say so (MM_ERR_SHAPE, nothing launched) instead of wrapping around."""
+    from medmamba_amd import _lib
+    lib, st = _lib.lib(), _lib.raw_stream()
+    B, D, L = 2, 192, 64
+    t = torch.zeros(4096, device=DEV)                     # never touched: the calls return before launching
+    p, big = t.data_ptr(), 1 << 26
+    assert lib.mm_ln_gate_fwd(p, D * big, big, p, D * L, L, p, p, 1e-5, p, D * L, L, p, p, B, D, L, st) == -2
+    assert lib.mm_ln_gate_bwd(p, D * L, L, p, D * L, L, p, D * L, L, p, p, p, p, p, D * big, big, p, D * L, L, p, B, D, L, st) == -2
+
+
 @pytest.mark.parametrize("cm", [False, True], ids=["bm", "cm"])
 @pytest.mark.parametrize("shape", [(64, 96, 14, 14), (3, 40, 7, 7), (2, 5, 16, 16), (2, 7, 5, 9), (1, 3, 1, 1), (2, 6, 1, 200), (3, 9, 37, 1),
                                    (2, 4, 16, 17), (1, 8, 56, 56), (2, 3, 33, 40)])
