@@ -229,7 +229,9 @@ int mm_plane_transpose(const float* src, int64_t src_sb, int64_t src_sd, float* 
 /* out_norm LayerNorm over the D channels (eps) + gate with SiLU(z) (MedMamba.py:300-301), channel-first:
  *   y[b,d,p] = ((m[b,d,p]-mu[b,p])*rstd[b,p]*gamma[d]+beta[d]) * silu(z[b,d,p]);  m,y (batch,D,L); z planes with batch
  *   stride z_sb; mu,rstd (batch,L) outputs.  Backward: dm, dz and per-workgroup
- *   partial sums ws[row*2*D + (0: dgamma, D: dbeta) + d] for row < mm_ln_gate_rows(batch, D, L) (the caller sums rows). */
+ *   partial sums ws[row*2*D + (0: dgamma, D: dbeta) + d] for row < mm_ln_gate_rows(batch, D, L) (the caller sums rows).
+ *   Channel strides (the *_sd arguments): 15 * stride + batch * L < 2^29 elements, else MM_ERR_SHAPE (a step of up to 16 channel
+ *   rows is addressed with 32-bit byte offsets; D * stride itself is not limited). */
 int mm_ln_gate_fwd(const float* m, int64_t m_sb, int64_t m_sd, const float* z, int64_t z_sb, int64_t z_sd, const float* gamma,
                    const float* beta, float eps, float* y, int64_t y_sb, int64_t y_sd, float* mu, float* rstd, int batch, int D,
                    int L, void* stream);
