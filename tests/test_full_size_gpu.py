@@ -127,17 +127,34 @@ def test_config3_S_batch64_full_size(monkeypatch):
     l0, g0 = _train_pass(net, xd, y)
     assert np.isfinite(l0)
     assert sum(1 for k in modules._CONV_WARM if k[2] is True) >= 4        # the four stage shapes were marked by the first backward
-    assert abs(l1 - l0) <= 2e-6 * abs(l0), (l0, l1)
-    _compare_grads(g0, g1, "two-stream vs single-stream")
+    # How far apart are two IDENTICAL passes on this box?  This library's kernels are deterministic; outside cudnn.deterministic
+    # MIOpen's picks for the dense convolutions are not on every box of the pool (atomics in the weight gradient always, in a
+    # data-path solver on some boxes: DESIGN.md §2).  The comparisons below cannot be tighter than that noise through 14 blocks of
+    # BatchNorm statistics and ReLU masks: each tolerance is the larger of its fixed value and ten times the measured noise.
+    l0b, g0b = _train_pass(net, xd, y)
+    noise_l2 = noise_mx = 0.0
+    for k in g0:
+        if k.endswith(("conv33conv33conv11.1.bias", "conv33conv33conv11.4.bias")):
+            continue
+        a, b = g0[k].double(), g0b[k].double()
+        if float(a.norm()) > 1e-12:
+            noise_l2 = max(noise_l2, float((a - b).norm() / a.norm()))
+            noise_mx = max(noise_mx, float((a - b).abs().max()) / max(1e-6, float(a.abs().max())))
+    noise_loss = abs(l0b - l0) / abs(l0)
+    del g0b
+    print(f"\n[two identical passes on this box: loss differs by {noise_loss:.1e} rel, gradients by at most {noise_l2:.1e} (l2) / {noise_mx:.1e} (max)]")
+    assert noise_loss <= 1e-5 and noise_l2 <= 5e-3 and noise_mx <= 2e-2          # noise, not a race
+    assert abs(l1 - l0) <= max(2e-6, 10 * noise_loss) * abs(l0), (l0, l1)
+    _compare_grads(g0, g1, "two-stream vs single-stream", l2_tol=max(3e-3, 10 * noise_l2), max_tol=max(2e-2, 10 * noise_mx))
     del g1
     for layout in ("bm", "cm"):
         monkeypatch.setattr(ops, "_LAYOUT", layout)
         l2, g2 = _train_pass(net, xd, y)
-        assert abs(l2 - l0) <= 5e-6 * abs(l0), (layout, l0, l2)
+        assert abs(l2 - l0) <= max(5e-6, 10 * noise_loss) * abs(l0), (layout, l0, l2)
         # the layouts differ in every GEMM's shape and summation order (batched vs one GEMM over batch*L columns); through 14
         # blocks with BatchNorm batch statistics and ReLU masks that is a few 1e-3 of a gradient's norm at this size
         # (7.2e-3 / 1.7e-2 measured; the oracle comparison below supports the same bound: l2 1.5e-2, max 5e-2)
-        _compare_grads(g0, g2, f"auto vs {layout}", l2_tol=1.5e-2, max_tol=5e-2)
+        _compare_grads(g0, g2, f"auto vs {layout}", l2_tol=max(1.5e-2, 10 * noise_l2), max_tol=max(5e-2, 10 * noise_mx))
         del g2
     # (iii) the launch plans of this configuration
     p1 = _plan(64, 4, 96, 3136, backward=True)

