@@ -98,6 +98,7 @@ def test_recorded_solutions_are_used_at_full_size(monkeypatch):
     if not blas._TABLE:
         pytest.skip("GEMM table not recorded for this rocBLAS build")
     try:
+        torch.backends.cudnn.deterministic = True      # the reference's mode (train.py:28-29): bitwise comparisons are meaningful
         torch.manual_seed(0)
         blk = modules.SS_Conv_SSM(hidden_dim=384, drop_path=0.0, norm_layer=torch.nn.LayerNorm).to(DEV).train()
         x = torch.randn(64, 14, 14, 384, device=DEV, requires_grad=True)
@@ -126,25 +127,10 @@ def test_recorded_solutions_are_used_at_full_size(monkeypatch):
         from medmamba_amd import _host
         assert _host.module() is not None
         o2, dx2, g2 = run()
-        o3, dx3, g3 = run()
-        # The SS2D branch (odd output channels after channel_shuffle, MedMamba.py:308-320; the right half of d(input)) is ours from end
-        # to end: same bits on both routes, always.  The conv branch contains MIOpen's dense convolutions, and which forward / data-
-        # gradient solver its search picks differs from box to box — some picks are not reproducible run to run (seen: max 1e-6 on the
-        # even channels between two identical calls); then the conv half is compared with a tolerance instead.
-        conv_repro = torch.equal(o3, o2) and torch.equal(dx3, dx2)
-        C2 = 192
-        assert torch.equal(o2[..., 1::2], o1[..., 1::2]) and torch.equal(dx2[..., C2:], dx1[..., C2:])
-        if conv_repro:
-            assert torch.equal(o2, o1) and torch.equal(dx2, dx1)
-        else:
-            assert torch.allclose(o2, o1, rtol=1e-4, atol=1e-5) and (dx2 - dx1).abs().max().item() <= 1e-4 * dx1.abs().max().item()
+        # (the whole test runs under cudnn.deterministic — see above —: MIOpen's default picks for the dense convolutions are not
+        # reproducible run to run on every box of the pool; in the reference's mode every gradient is)
+        assert torch.equal(o2, o1) and torch.equal(dx2, dx1)
         for k in g1:
-            if k in ("conv33conv33conv11.1.weight", "conv33conv33conv11.4.weight"):
-                continue          # MIOpen's weight-gradient kernels accumulate with atomics
-            if k.startswith("conv33conv33conv11") and not conv_repro:
-                if k not in ("conv33conv33conv11.1.bias", "conv33conv33conv11.4.bias"):     # (true gradient zero: rounding noise)
-                    assert (g2[k] - g1[k]).abs().max().item() <= 1e-3 * max(1e-4, g1[k].abs().max().item()), k
-                continue
             assert torch.equal(g2[k], g1[k]), k
         assert torch.allclose(o1, o0, rtol=1e-4, atol=1e-4)
         assert (dx1 - dx0).abs().max().item() <= 2e-3 * dx0.abs().max().item()
@@ -153,6 +139,7 @@ def test_recorded_solutions_are_used_at_full_size(monkeypatch):
                 continue          # a conv bias in front of a BatchNorm: the true gradient is exactly zero, what is computed is rounding noise
             assert (g1[k] - g0[k]).abs().max().item() <= 2e-3 * max(1e-4, g0[k].abs().max().item()), k
     finally:
+        torch.backends.cudnn.deterministic = False
         torch.cuda.tunable.enable(False)
         blas.clear()
 

@@ -118,8 +118,14 @@ def test_config3_S_batch64_full_size(monkeypatch):
     want = _oracle_logits(net, x, pick, cfg["depths"])
     assert np.isfinite(got).all()
     assert np.abs(got[pick] - want).max() <= 1e-3 * max(1.0, np.abs(want).max()), np.abs(got[pick] - want).max()
-    # (ii) train mode at full size: schedules and layouts agree
+    # (ii) train mode at full size: schedules and layouts agree.  Under torch.backends.cudnn.deterministic — the mode the reference
+    # trains in (train.py:28-29) — every kernel of the step is reproducible, so the two-stream schedule must give the SAME BITS as
+    # the single-stream one, pass after pass: a missed cross-stream dependency or an early buffer reuse cannot hide in a
+    # tolerance.  (Outside that mode MIOpen's atomics-based weight- and data-gradient solvers make two identical passes differ by
+    # ~1e-5 of a gradient's norm most of the time and by up to 1e-2 now and then on this stack — measured with tools/run_to_run_noise.py
+    #  — which is why this comparison used to flake at any fixed tolerance.)
     net.train()
+    monkeypatch.setattr(torch.backends.cudnn, "deterministic", True)
     # single-stream first: the first pass over a conv shape runs on one stream anyway (MIOpen's solver search, modules.py)
     monkeypatch.setattr(modules, "_TWO_STREAMS", False)
     l1, g1 = _train_pass(net, xd, y)
@@ -127,35 +133,29 @@ def test_config3_S_batch64_full_size(monkeypatch):
     l0, g0 = _train_pass(net, xd, y)
     assert np.isfinite(l0)
     assert sum(1 for k in modules._CONV_WARM if k[2] is True) >= 4        # the four stage shapes were marked by the first backward
-    # How far apart are two IDENTICAL passes on this box?  This library's kernels are deterministic; outside cudnn.deterministic
-    # MIOpen's picks for the dense convolutions are not on every box of the pool (atomics in the weight gradient always, in a
-    # data-path solver on some boxes: DESIGN.md §2).  The comparisons below cannot be tighter than that noise through 14 blocks of
-    # BatchNorm statistics and ReLU masks: each tolerance is the larger of its fixed value and ten times the measured noise.
     l0b, g0b = _train_pass(net, xd, y)
-    noise_l2 = noise_mx = 0.0
+    assert l1 == l0 == l0b, (l1, l0, l0b)
     for k in g0:
-        if k.endswith(("conv33conv33conv11.1.bias", "conv33conv33conv11.4.bias")):
-            continue
-        a, b = g0[k].double(), g0b[k].double()
-        if float(a.norm()) > 1e-12:
-            noise_l2 = max(noise_l2, float((a - b).norm() / a.norm()))
-            noise_mx = max(noise_mx, float((a - b).abs().max()) / max(1e-6, float(a.abs().max())))
-    noise_loss = abs(l0b - l0) / abs(l0)
-    del g0b
-    print(f"\n[two identical passes on this box: loss differs by {noise_loss:.1e} rel, gradients by at most {noise_l2:.1e} (l2) / {noise_mx:.1e} (max)]")
-    assert noise_loss <= 1e-5 and noise_l2 <= 5e-3 and noise_mx <= 2e-2          # noise, not a race
-    assert abs(l1 - l0) <= max(2e-6, 10 * noise_loss) * abs(l0), (l0, l1)
-    _compare_grads(g0, g1, "two-stream vs single-stream", l2_tol=max(3e-3, 10 * noise_l2), max_tol=max(2e-2, 10 * noise_mx))
-    del g1
+        assert torch.equal(g0[k], g1[k]), ("two-stream vs single-stream", k)
+        assert torch.equal(g0[k], g0b[k]), ("two-stream, pass after pass", k)
+    del g1, g0b
     for layout in ("bm", "cm"):
         monkeypatch.setattr(ops, "_LAYOUT", layout)
         l2, g2 = _train_pass(net, xd, y)
-        assert abs(l2 - l0) <= max(5e-6, 10 * noise_loss) * abs(l0), (layout, l0, l2)
+        assert abs(l2 - l0) <= 5e-6 * abs(l0), (layout, l0, l2)
         # the layouts differ in every GEMM's shape and summation order (batched vs one GEMM over batch*L columns); through 14
         # blocks with BatchNorm batch statistics and ReLU masks that is a few 1e-3 of a gradient's norm at this size
         # (7.2e-3 / 1.7e-2 measured; the oracle comparison below supports the same bound: l2 1.5e-2, max 5e-2)
-        _compare_grads(g0, g2, f"auto vs {layout}", l2_tol=max(1.5e-2, 10 * noise_l2), max_tol=max(5e-2, 10 * noise_mx))
+        _compare_grads(g0, g2, f"auto vs {layout}", l2_tol=1.5e-2, max_tol=5e-2)
         del g2
+    monkeypatch.setattr(ops, "_LAYOUT", "auto")
+    # the default mode (what bench.py measures: MIOpen free to pick its atomics-based solvers): same loss, gradients within that
+    # mode's own noise of the reproducible ones
+    monkeypatch.setattr(torch.backends.cudnn, "deterministic", False)
+    l3, g3 = _train_pass(net, xd, y)
+    assert abs(l3 - l0) <= 2e-5 * abs(l0), (l0, l3)
+    _compare_grads(g0, g3, "default mode vs cudnn.deterministic", l2_tol=5e-2, max_tol=2.5e-1)
+    del g3
     # (iii) the launch plans of this configuration
     p1 = _plan(64, 4, 96, 3136, backward=True)
     assert p1["vec"] == 1 and p1["ns"] == 2 and p1["waves"] == 12 and p1["blocks"] == 256, p1      # one workgroup per direction

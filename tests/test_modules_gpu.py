@@ -94,9 +94,11 @@ def test_seed_kat_full_model_logits(size):
 def test_two_stream_blocks_match_single_stream(monkeypatch):
     """The conv branch runs on a side HIP stream (modules.SS_Conv_SSM.forward): same loss and grads as the
     single-stream schedule, run after run with the allocator churned in between (a missed cross-stream dependency or
-    an early buffer reuse shows here).  Weights stay fixed: with optimizer steps in between, the 1e-7 run-to-run
-    noise of the atomics flips ReLU masks and the comparison turns chaotic in either schedule."""
+    an early buffer reuse shows here).  Run under cudnn.deterministic (the reference's mode, train.py:28-29), where every kernel of
+    the step is reproducible: the schedules must agree BIT FOR BIT (outside that mode MIOpen's atomics-based solvers add noise of
+    1e-5 ... 1e-2 of a gradient's norm on this stack, and a tolerance would have to be that loose)."""
     from medmamba_amd import modules
+    monkeypatch.setattr(torch.backends.cudnn, "deterministic", True)
     torch.manual_seed(3)
     net = modules.VSSM(num_classes=5, depths=[2, 2, 2, 2], dims=[32, 64, 128, 256], drop_path_rate=0.0).to(DEV).train()
     x = torch.randn(8, 3, 128, 128, device=DEV)
@@ -115,10 +117,9 @@ def test_two_stream_blocks_match_single_stream(monkeypatch):
     l0, g0 = run(False, 0)
     for it, two in enumerate([True, True, False, True, True, True], start=1):
         l, g = run(two, it)
-        assert abs(l - l0) <= 1e-5 * abs(l0), (it, l, l0)      # (a nondeterministic MIOpen forward pick costs ~1e-6: DESIGN.md §2)
+        assert l == l0, (it, l, l0)
         for k in g0:
-            scale = max(1e-4, float(g0[k].abs().max()))
-            assert float((g0[k] - g[k]).abs().max()) <= 2e-3 * scale, (it, two, k)
+            assert torch.equal(g0[k], g[k]), (it, two, k)
 
 
 @pytest.mark.parametrize("layout", ["bm", "cm"])
