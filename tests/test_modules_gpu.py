@@ -95,8 +95,8 @@ def test_two_stream_blocks_match_single_stream(monkeypatch):
     """The conv branch runs on a side HIP stream (modules.SS_Conv_SSM.forward): same loss and grads as the
     single-stream schedule, run after run with the allocator churned in between (a missed cross-stream dependency or
     an early buffer reuse shows here).  Run under cudnn.deterministic (the reference's mode, train.py:28-29), where every kernel of
-    the step is reproducible: the schedules must agree BIT FOR BIT (outside that mode MIOpen's atomics-based solvers add noise of
-    1e-5 ... 1e-2 of a gradient's norm on this stack, and a tolerance would have to be that loose)."""
+    the step is reproducible: the schedules must agree BIT FOR BIT (outside that mode MIOpen's picks add run-to-run noise of 1e-5 ...
+    1e-2 of a gradient's norm on this stack — DESIGN.md §2 — and a tolerance would have to be that loose)."""
     from medmamba_amd import modules
     monkeypatch.setattr(torch.backends.cudnn, "deterministic", True)
     torch.manual_seed(3)
