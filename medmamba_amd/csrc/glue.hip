@@ -1398,11 +1398,12 @@ __device__ __forceinline__ float row_sum(float v) {
   return v;
 }
 
-constexpr int kLnNV = 8;   // channels per lane (C2 <= 8 * TPR)
+constexpr int kLnNV = 8;   // most channels per lane (C2 <= 8 * TPR); the kernels are instantiated for NV = 3, 6, 8 slots per lane: 48 / 96 (16
+                           // lanes per row) and 192 / 384 channels (64) of the S / T stages need 3 / 6 — the idle slots still cost their instructions
 
 // (device bodies with a virtual block index / grid size: mm_block_split_* runs the transpose of the left half and the LayerNorm of
 //  the right half — independent of each other — as the two block ranges of ONE launch)
-template <int TPR>
+template <int TPR, int NV>
 __device__ __forceinline__ void ln_half_fwd_body(int vblk, int vgrid, const float* __restrict__ inp, const float* __restrict__ gamma,
                                                  const float* __restrict__ beta, float eps, float* __restrict__ rn,
                                                  float* __restrict__ mu_out, float* __restrict__ rstd_out,
@@ -1411,37 +1412,37 @@ __device__ __forceinline__ void ln_half_fwd_body(int vblk, int vgrid, const floa
   const int lane = threadIdx.x & 63, lr = lane % TPR, lrow = lane / TPR;
   const int64_t wave_global = (int64_t)vblk * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = (int64_t)vgrid * 4;
   const rsrc_t rgam = make_rsrc(gamma, (int64_t)C2 * 4), rbet = make_rsrc(beta, (int64_t)C2 * 4);
-  float gm[kLnNV], bt[kLnNV];
+  float gm[NV], bt[NV];
 #pragma unroll
-  for (int k = 0; k < kLnNV; ++k) {
+  for (int k = 0; k < NV; ++k) {
     gm[k] = ldb(rgam, (lr + k * TPR) * 4);           // beyond C2: 0
     bt[k] = ldb(rbet, (lr + k * TPR) * 4);
   }
   for (int64_t rg = wave_global; rg * RPW < nrows; rg += nwaves) {
     const int64_t row0 = rg * RPW, row = row0 + lrow;               // row0: wave-uniform
     const bool rok = row < nrows;
-    // the RPW rows of this wave through one descriptor (no branch around a load: all kLnNV loads of a lane in flight, §4.4)
+    // the RPW rows of this wave through one descriptor (no branch around a load: all NV loads of a lane in flight, §4.4)
     const int nr = (int)(nrows - row0 < RPW ? nrows - row0 : RPW);
     const rsrc_t rx = make_rsrc(inp + row0 * C + C2, ((int64_t)(nr - 1) * C + C2) * 4);
-    float x[kLnNV], s = 0.f;
+    float x[NV], s = 0.f;
 #pragma unroll
-    for (int k = 0; k < kLnNV; ++k) {
+    for (int k = 0; k < NV; ++k) {
       const int c = lr + k * TPR;
       x[k] = ldb(rx, (rok && c < C2) ? (lrow * C + c) * 4 : kOOB);
     }
 #pragma unroll
-    for (int k = 0; k < kLnNV; ++k) s += x[k];
+    for (int k = 0; k < NV; ++k) s += x[k];
     const float mean = row_sum<TPR>(s) / C2;
     float v = 0.f;
 #pragma unroll
-    for (int k = 0; k < kLnNV; ++k) {
+    for (int k = 0; k < NV; ++k) {
       const float dlt = (lr + k * TPR < C2) ? x[k] - mean : 0.f;
       v = fmaf(dlt, dlt, v);
     }
     const float rstd = __builtin_amdgcn_rsqf(row_sum<TPR>(v) / C2 + eps);
     if (rok) {
 #pragma unroll
-      for (int k = 0; k < kLnNV; ++k) {
+      for (int k = 0; k < NV; ++k) {
         const int c = lr + k * TPR;
         if (c < C2) rn[row * C2 + c] = (x[k] - mean) * rstd * gm[k] + bt[k];
       }
@@ -1451,7 +1452,7 @@ __device__ __forceinline__ void ln_half_fwd_body(int vblk, int vgrid, const floa
 }
 
 // d_inp[row, C2 + c] = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = d_rn * gamma;  per-wave partial dgamma / dbeta rows.
-template <int TPR>
+template <int TPR, int NV>
 __device__ __forceinline__ void ln_half_bwd_body(int vblk, int vgrid, const float* __restrict__ drn, const float* __restrict__ inp,
                                                  const float* __restrict__ gamma, const float* __restrict__ mu_in,
                                                  const float* __restrict__ rstd_in, const float* __restrict__ dres,
@@ -1461,25 +1462,25 @@ __device__ __forceinline__ void ln_half_bwd_body(int vblk, int vgrid, const floa
   const int lane = threadIdx.x & 63, lr = lane % TPR, lrow = lane / TPR;
   const int64_t wave_global = (int64_t)vblk * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = (int64_t)vgrid * 4;
   const rsrc_t rgam = make_rsrc(gamma, (int64_t)C2 * 4);
-  float gm[kLnNV], ag[kLnNV], ab[kLnNV];
+  float gm[NV], ag[NV], ab[NV];
 #pragma unroll
-  for (int k = 0; k < kLnNV; ++k) {
+  for (int k = 0; k < NV; ++k) {
     gm[k] = ldb(rgam, (lr + k * TPR) * 4);           // beyond C2: 0
     ag[k] = 0.f; ab[k] = 0.f;
   }
   for (int64_t rg = wave_global; rg * RPW < nrows; rg += nwaves) {
     const int64_t row0 = rg * RPW, row = row0 + lrow;               // row0: wave-uniform
     const bool rok = row < nrows;
-    // the RPW rows of this wave through one descriptor per operand: 2-3 x kLnNV loads of a lane in flight together (§4.4)
+    // the RPW rows of this wave through one descriptor per operand: 2-3 x NV loads of a lane in flight together (§4.4)
     const int nr = (int)(nrows - row0 < RPW ? nrows - row0 : RPW);
     const int64_t half = ((int64_t)(nr - 1) * C + C2) * 4;
     const rsrc_t rd = make_rsrc(drn + row0 * C2, (int64_t)nr * C2 * 4), rx = make_rsrc(inp + row0 * C + C2, half),
                  rr = make_rsrc(dres ? dres + row0 * C + C2 : nullptr, dres ? half : 0), rst = make_rsrc(mu_in + row0, (int64_t)nr * 4),
                  rrs = make_rsrc(rstd_in + row0, (int64_t)nr * 4);
     const float mean = ldb(rst, lrow * 4), rstd = ldb(rrs, lrow * 4);       // rows beyond nrows: 0
-    float xh[kLnNV], g[kLnNV], dv[kLnNV], rv[kLnNV], s1 = 0.f, s2 = 0.f;
+    float xh[NV], g[NV], dv[NV], rv[NV], s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int k = 0; k < kLnNV; ++k) {
+    for (int k = 0; k < NV; ++k) {
       const int c = lr + k * TPR;
       const bool ok = rok && c < C2;
       dv[k] = ldb(rd, ok ? (lrow * C2 + c) * 4 : kOOB);
@@ -1487,7 +1488,7 @@ __device__ __forceinline__ void ln_half_bwd_body(int vblk, int vgrid, const floa
       rv[k] = ldb(rr, ok ? (lrow * C + c) * 4 : kOOB);
     }
 #pragma unroll
-    for (int k = 0; k < kLnNV; ++k) {
+    for (int k = 0; k < NV; ++k) {
       const bool ok = rok && lr + k * TPR < C2;
       const float d = dv[k];
       xh[k] = ok ? (xh[k] - mean) * rstd : 0.f;
@@ -1500,7 +1501,7 @@ __device__ __forceinline__ void ln_half_bwd_body(int vblk, int vgrid, const floa
     const float c1 = row_sum<TPR>(s1) / C2, c2 = row_sum<TPR>(s2) / C2;
     if (rok) {
 #pragma unroll
-      for (int k = 0; k < kLnNV; ++k) {
+      for (int k = 0; k < NV; ++k) {
         const int c = lr + k * TPR;
         if (c < C2) dinp[row * C + C2 + c] = rstd * (g[k] - c1 - xh[k] * c2) + rv[k];
       }
@@ -1510,7 +1511,7 @@ __device__ __forceinline__ void ln_half_bwd_body(int vblk, int vgrid, const floa
   extern __shared__ float sred[];                       // [4 waves][2*C2]: one row per wave (plain stores), summed in wave order
   const int wv = threadIdx.x >> 6;
 #pragma unroll
-  for (int k = 0; k < kLnNV; ++k) {
+  for (int k = 0; k < NV; ++k) {
     float a = ag[k], bsum = ab[k];
     if constexpr (TPR == 16) {
       a += __shfl_xor(a, 16); a += __shfl_xor(a, 32);
@@ -1579,24 +1580,24 @@ __device__ __forceinline__ void half_transpose_body(int vblk, const float* __res
 }
 
 // blocks [0, nT): NHWC left half -> NCHW (optionally with the folded BatchNorm affine); blocks [nT, grid): ln_1 of the right half
-template <int TPR>
+template <int TPR, int NV>
 __global__ __launch_bounds__(256) void block_split_fwd_kernel(int nT, const float* __restrict__ inp, const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, float eps,
                                                               const float* __restrict__ left_affine, float* __restrict__ left_nchw,
                                                               float* __restrict__ rn, float* __restrict__ mu, float* __restrict__ rstd,
                                                               int64_t nrows, int P, int C, int C2) {
   if ((int)blockIdx.x < nT) half_transpose_body<false>(blockIdx.x, inp, left_nchw, left_affine, P, C, C2);
-  else ln_half_fwd_body<TPR>(blockIdx.x - nT, gridDim.x - nT, inp, gamma, beta, eps, rn, mu, rstd, nrows, C, C2);
+  else ln_half_fwd_body<TPR, NV>(blockIdx.x - nT, gridDim.x - nT, inp, gamma, beta, eps, rn, mu, rstd, nrows, C, C2);
 }
 // blocks [0, nT): d(left) NCHW -> d(inp)[..., :C2] (+ residual gradient); blocks [nT, grid): LayerNorm backward into d(inp)[..., C2:]
-template <int TPR>
+template <int TPR, int NV>
 __global__ __launch_bounds__(256) void block_split_bwd_kernel(int nT, const float* __restrict__ dleft_nchw, const float* __restrict__ drn,
                                                               const float* __restrict__ dres, const float* __restrict__ inp,
                                                               const float* __restrict__ gamma, const float* __restrict__ mu,
                                                               const float* __restrict__ rstd, float* __restrict__ dinp,
                                                               float* __restrict__ ws, int64_t nrows, int P, int C, int C2) {
   if ((int)blockIdx.x < nT) half_transpose_body<true>(blockIdx.x, dleft_nchw, dinp, dres, P, C, C2);
-  else ln_half_bwd_body<TPR>(blockIdx.x - nT, gridDim.x - nT, drn, inp, gamma, mu, rstd, dres, dinp, ws, nrows, C, C2);
+  else ln_half_bwd_body<TPR, NV>(blockIdx.x - nT, gridDim.x - nT, drn, inp, gamma, mu, rstd, dres, dinp, ws, nrows, C, C2);
 }
 
 inline int ln_half_grid(int64_t nrows, int tpr) {
@@ -1622,8 +1623,12 @@ int mm_block_split_fwd(const float* inp, const float* gamma, const float* beta, 
   const int C = 2 * C2;
   const int64_t nrows = (int64_t)batch * P;
   const int nT = ((P + 31) / 32) * ((C2 + 31) / 32) * batch;
-  if (C2 <= 128) hipLaunchKernelGGL(block_split_fwd_kernel<16>, dim3(nT + ln_half_grid(nrows, 16)), dim3(256), 0, s, nT, inp, gamma, beta, eps, left_affine, left_nchw, rn, mu, rstd, nrows, P, C, C2);
-  else hipLaunchKernelGGL(block_split_fwd_kernel<64>, dim3(nT + ln_half_grid(nrows, 64)), dim3(256), 0, s, nT, inp, gamma, beta, eps, left_affine, left_nchw, rn, mu, rstd, nrows, P, C, C2);
+  const int tpr = C2 <= 128 ? 16 : 64, need = (C2 + tpr - 1) / tpr;
+  const dim3 grid(nT + ln_half_grid(nrows, tpr));
+#define MM_BS_FWD(TPR_, NV_) hipLaunchKernelGGL((block_split_fwd_kernel<TPR_, NV_>), grid, dim3(256), 0, s, nT, inp, gamma, beta, eps, left_affine, left_nchw, rn, mu, rstd, nrows, P, C, C2)
+  if (tpr == 16) { if (need <= 3) MM_BS_FWD(16, 3); else if (need <= 6) MM_BS_FWD(16, 6); else MM_BS_FWD(16, 8); }
+  else { if (need <= 3) MM_BS_FWD(64, 3); else if (need <= 6) MM_BS_FWD(64, 6); else MM_BS_FWD(64, 8); }
+#undef MM_BS_FWD
   return (int)hipGetLastError();
 }
 
@@ -1636,8 +1641,12 @@ int mm_block_split_bwd(const float* dleft_nchw, const float* drn, const float* d
   const int C = 2 * C2;
   const int64_t nrows = (int64_t)batch * P;
   const int nT = ((P + 31) / 32) * ((C2 + 31) / 32) * batch;
-  if (C2 <= 128) hipLaunchKernelGGL(block_split_bwd_kernel<16>, dim3(nT + ln_half_grid(nrows, 16)), dim3(256), 8 * C2 * sizeof(float), s, nT, dleft_nchw, drn, dres, inp, gamma, mu, rstd, dinp, ws, nrows, P, C, C2);
-  else hipLaunchKernelGGL(block_split_bwd_kernel<64>, dim3(nT + ln_half_grid(nrows, 64)), dim3(256), 8 * C2 * sizeof(float), s, nT, dleft_nchw, drn, dres, inp, gamma, mu, rstd, dinp, ws, nrows, P, C, C2);
+  const int tpr = C2 <= 128 ? 16 : 64, need = (C2 + tpr - 1) / tpr;
+  const dim3 grid(nT + ln_half_grid(nrows, tpr));
+#define MM_BS_BWD(TPR_, NV_) hipLaunchKernelGGL((block_split_bwd_kernel<TPR_, NV_>), grid, dim3(256), 8 * C2 * sizeof(float), s, nT, dleft_nchw, drn, dres, inp, gamma, mu, rstd, dinp, ws, nrows, P, C, C2)
+  if (tpr == 16) { if (need <= 3) MM_BS_BWD(16, 3); else if (need <= 6) MM_BS_BWD(16, 6); else MM_BS_BWD(16, 8); }
+  else { if (need <= 3) MM_BS_BWD(64, 3); else if (need <= 6) MM_BS_BWD(64, 6); else MM_BS_BWD(64, 8); }
+#undef MM_BS_BWD
   return (int)hipGetLastError();
 }
 
