@@ -1117,7 +1117,7 @@ inline LnPlan plan_ln(int batch, int D, int L, bool bwd) {
       static const int pw32 = [] { const char* e = getenv("MM_LN_PW32"); return e ? atoi(e) : 1; }();
       const bool wide = lpp == 16 && (bwd ? pw32 != 3 && pw32 != 0 : pw32 != 0);   // MM_LN_PW32: 0 = never, 3 = forward only (A/B)
       pl.pw = wide ? 32 : 16; pl.nw = wide ? 8 : lpp / 4; pl.ppb = pl.pw;
-      pl.cpl = need <= 16 ? 16 : need <= 24 ? 24 : need <= 32 ? 32 : 48;
+      pl.cpl = (wide && need <= 12) ? 12 : need <= 16 ? 16 : need <= 24 ? 24 : need <= 32 ? 32 : 48;   // 12: D = 192 without idle slots
       return pl;
     }
   }
@@ -1163,6 +1163,7 @@ int launch_ln_fwdc(const LnPlan& pl, dim3 grid, hipStream_t s, const float* m, i
 #define MM_LN_FWDC32(CPL_) hipLaunchKernelGGL((ln_gate_fwdc_kernel<32, 8, CPL_>), grid, dim3(512), 0, s, MM_LN_ARGS_F)
   if (pl.pw == 32) {
     switch (pl.cpl) {
+      case 12: MM_LN_FWDC32(12); break;
       case 16: MM_LN_FWDC32(16); break;
       case 24: MM_LN_FWDC32(24); break;
       default: MM_LN_FWDC32(32); break;
@@ -1199,7 +1200,7 @@ int launch_ln_bwdc(const LnPlan& pl, dim3 grid, hipStream_t s, const float* dy, 
     if (pl.cpl == 16) MM_LN_BWDC64(16); else if (pl.cpl == 24) MM_LN_BWDC64(24); else MM_LN_BWDC64(32);
 #undef MM_LN_BWDC64
   } else if (pl.pw == 32) {
-    if (pl.cpl == 16) MM_LN_BWDC32(16); else MM_LN_BWDC32(24);
+    if (pl.cpl == 12) MM_LN_BWDC32(12); else if (pl.cpl == 16) MM_LN_BWDC32(16); else MM_LN_BWDC32(24);
   } else if (pl.nw == 4) {
     if (pl.cpl == 16) MM_LN_BWDC(4, 16); else MM_LN_BWDC(4, 24);
   } else {

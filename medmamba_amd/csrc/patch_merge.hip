@@ -329,7 +329,9 @@ int mm_patch_merge_ln_rows(int batch, int H, int W) { return 4 * pm_grid((int64_
     const dim3 grid(pm_grid(nrows)), block(256);                                                                      \
     if (nv <= 1) hipLaunchKernelGGL(KERNEL<1>, grid, block, 0, s, __VA_ARGS__);                                       \
     else if (nv <= 2) hipLaunchKernelGGL(KERNEL<2>, grid, block, 0, s, __VA_ARGS__);                                  \
+    else if (nv <= 3) hipLaunchKernelGGL(KERNEL<3>, grid, block, 0, s, __VA_ARGS__);   /* 4C = 768: no idle slot */   \
     else if (nv <= 4) hipLaunchKernelGGL(KERNEL<4>, grid, block, 0, s, __VA_ARGS__);                                  \
+    else if (nv <= 6) hipLaunchKernelGGL(KERNEL<6>, grid, block, 0, s, __VA_ARGS__);   /* 4C = 1536 */                \
     else hipLaunchKernelGGL(KERNEL<8>, grid, block, 0, s, __VA_ARGS__);                                               \
   } while (0)
 
