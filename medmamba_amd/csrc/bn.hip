@@ -227,11 +227,11 @@ __global__ __launch_bounds__(512) void bn_fused_fwd_kernel(const float* __restri
   float v[VPT];
   int64_t off[VPT];
   float sum = 0.f;
+  DivMod bp(threadIdx.x, 512, HW);                // (image, position) of element e = threadIdx.x + 512 i: one division, not VPT
 #pragma unroll
-  for (int i = 0; i < VPT; ++i) {
+  for (int i = 0; i < VPT; ++i, bp.next()) {
     const int e = threadIdx.x + 512 * i;
-    const int b = e / HW, p = e - b * HW;
-    off[i] = e < n ? ((int64_t)b * C + c) * HW + p : -1;
+    off[i] = e < n ? ((int64_t)bp.q * C + c) * HW + bp.r : -1;
     v[i] = off[i] >= 0 ? x[off[i]] : 0.f;
     sum += v[i];
   }
@@ -267,11 +267,11 @@ __global__ __launch_bounds__(512) void bn_fused_bwd_kernel(const float* __restri
   float gg[VPT], xh[VPT];
   int64_t off[VPT];
   float s1 = 0.f, s2 = 0.f;
+  DivMod bp(threadIdx.x, 512, HW);
 #pragma unroll
-  for (int i = 0; i < VPT; ++i) {
+  for (int i = 0; i < VPT; ++i, bp.next()) {
     const int e = threadIdx.x + 512 * i;
-    const int b = e / HW, p = e - b * HW;
-    off[i] = e < n ? ((int64_t)b * C + c) * HW + p : -1;
+    off[i] = e < n ? ((int64_t)bp.q * C + c) * HW + bp.r : -1;
     const float xv = off[i] >= 0 ? x[off[i]] : 0.f;
     const float d = off[i] >= 0 ? dy[off[i]] : 0.f;
     xh[i] = (xv - mean) * rstd;
@@ -294,7 +294,8 @@ inline int bn_fused_vpt(int batch, int C, int HW) {        // 0: the two-kernel 
   static const int enabled = [] { const char* e = getenv("MM_BN_FUSED"); return e ? atoi(e) : 1; }();   // A/B switch
   const int64_t n = (int64_t)batch * HW;
   if (!enabled || C < 64 || n > 512 * 32) return 0;
-  return n <= 512 * 8 ? 8 : n <= 512 * 16 ? 16 : 32;
+  // slots per thread: 7 / 25 are the 7x7 and 14x14 stages at 64 images (3136 and 12544 values per channel) without idle slots
+  return n <= 512 * 7 ? 7 : n <= 512 * 8 ? 8 : n <= 512 * 16 ? 16 : n <= 512 * 25 ? 25 : 32;
 }
 
 inline BnGeom bn_geom(int batch, int C, int HW) {
@@ -324,8 +325,10 @@ int mm_bn_relu_fwd(const float* x, const float* gamma, const float* beta, float 
   switch (bn_fused_vpt(batch, C, HW)) {
 #define MM_BN_FF(V) hipLaunchKernelGGL(bn_fused_fwd_kernel<V>, dim3(C), dim3(512), 0, s, x, gamma, beta, eps, momentum, running_mean, \
                                        running_var, y, mean, rstd, relu, pre_bias, batch, C, HW); return (int)hipGetLastError()
+    case 7: MM_BN_FF(7);
     case 8: MM_BN_FF(8);
     case 16: MM_BN_FF(16);
+    case 25: MM_BN_FF(25);
     case 32: MM_BN_FF(32);
 #undef MM_BN_FF
     default: break;
@@ -362,8 +365,10 @@ int mm_bn_relu_bwd(const float* dy, const float* x, const float* gamma, const fl
   switch (vpt) {
 #define MM_BN_FB(V) hipLaunchKernelGGL(bn_fused_bwd_kernel<V>, dim3(C), dim3(512), 0, s, dy, x, mean, rstd, gamma, beta, relu, dx, dgamma, \
                                        dbeta, dxsum, batch, C, HW); return (int)hipGetLastError()
+    case 7: MM_BN_FB(7);
     case 8: MM_BN_FB(8);
     case 16: MM_BN_FB(16);
+    case 25: MM_BN_FB(25);
     case 32: MM_BN_FB(32);
 #undef MM_BN_FB
     default: break;

@@ -143,14 +143,6 @@ int mm_shuffle_residual_bwd(const float* dout, float* dleft, float* dssm, int64_
 // =====================================================================================================
 namespace {
 
-// (quotient, remainder) of a loop index that advances by a fixed step: one division before the loop instead of one per
-// element (an integer division by a runtime value is ~25 VALU instructions; these kernels do ~60 of real work per element)
-struct DivMod {
-  int q, r, dq, dr, d;
-  __device__ __forceinline__ DivMod(int start, int step, int div) : q(start / div), r(start % div), dq(step / div), dr(step % div), d(div) {}
-  __device__ __forceinline__ void next() { q += dq; r += dr; if (r >= d) { r -= d; ++q; } }
-};
-
 // Plane loads of the depthwise kernels: a bounds-checked buffer load per element (an offset of kOOB reads 0: the zero border, the
 // tail of a loop, a missing plane) — no branch around the load, so that the U loads of an unrolled chunk are ALL in flight before
 // the first one is used.  (Round 4: the loops used to run `global_load_dword; s_waitcnt vmcnt(0)` per iteration — one load in flight
