@@ -729,6 +729,17 @@ class ConvBiasFn(torch.autograd.Function):
                            "mm_im2col3x3")
             dyg = dy.reshape(B, K, HW) if gs == 1 else dy.reshape(B // gs, gs, K, HW).transpose(1, 2).reshape(B // gs, K, gs * HW)
             dw = sum_lead(torch.bmm(dyg, cols.transpose(1, 2))).view(w.shape)
+        elif (torch.backends.cudnn.deterministic and ctx.needs_input_grad[1] and not ctx.needs_input_grad[0] and x.is_cuda
+              and list(w.shape[2:]) == stride and padding == [0, 0] and dilation == [1, 1]
+              and x.shape[2] % stride[0] == 0 and x.shape[3] % stride[1] == 0):
+            # deterministic mode, a patch convolution (kernel = stride: PatchEmbed2D's 4x4 / 4, MedMamba.py:62) whose input needs no
+            # gradient: MIOpen's reproducible weight gradient is a per-image im2col + GEMM (128 launches, 2 ms per MedMamba-S step at
+            # 64 images); the patches do not overlap, so im2col is one permuted copy and the gradient one batched GEMM + an ordered sum
+            B, C, H, W = x.shape
+            kh, kw = stride
+            cols = x.view(B, C, H // kh, kh, W // kw, kw).permute(0, 1, 3, 5, 2, 4).reshape(B, C * kh * kw, (H // kh) * (W // kw))
+            dw = sum_lead(torch.bmm(dy.reshape(B, dy.shape[1], -1), cols.transpose(1, 2))).view(w.shape)
+            dx = None
         else:
             dx, dw, _ = torch.ops.aten.convolution_backward(dy, x, w, None, stride, padding, dilation, False, [0, 0], 1,
                                                             [ctx.needs_input_grad[0], ctx.needs_input_grad[1], False])

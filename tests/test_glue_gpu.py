@@ -407,6 +407,29 @@ def test_cross_merge_and_plane_transpose_kernels(shape, cm):
     assert torch.equal(src[:, :D], before)
 
 
+def test_patch_embed_weight_gradient_in_deterministic_mode(monkeypatch):
+    """cudnn.deterministic (the reference's mode): PatchEmbed2D's 4x4 / stride-4 conv (MedMamba.py:62) gets its weight gradient from
+    one permuted copy + one batched GEMM + an ordered sum (ops.ConvBiasFn) instead of MIOpen's per-image solver — the same values
+    as the default mode's, the same bits run after run."""
+    from medmamba_amd import modules
+    torch.manual_seed(4)
+    pe = modules.PatchEmbed2D(patch_size=4, in_chans=3, embed_dim=96, norm_layer=torch.nn.LayerNorm).to(DEV)
+    x = torch.randn(8, 3, 64, 96, device=DEV)
+    g = torch.randn(8, 16, 24, 96, device=DEV)
+
+    def run():
+        pe.zero_grad(set_to_none=True)
+        pe(x).backward(g)
+        return {k: p.grad.clone() for k, p in pe.named_parameters()}
+
+    ref = run()
+    monkeypatch.setattr(torch.backends.cudnn, "deterministic", True)
+    a, b = run(), run()
+    for k in ref:
+        assert torch.equal(a[k], b[k]), k
+        assert float((a[k] - ref[k]).abs().max()) <= 2e-4 * max(1e-3, float(ref[k].abs().max())), k
+
+
 def test_patch_embed_permute_layernorm_kernel():
     """PatchEmbed2D's permute + LayerNorm (MedMamba.py:70-76) as one kernel each way against the op chain: model widths (96, 128),
     widths that are not a multiple of 64, the 512 limit, plane sizes that are not a multiple of the 32-position tile; and the
