@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Regenerate medmamba_amd/tuning/gemm_gfx950.csv: run MedMamba-S training steps (64 x 224^2, the bench workload) with
 PyTorch TunableOp timing every rocBLAS / hipBLASLt solution for each GEMM shape it meets.  Run on ONE MI355X.
-usage: python tools/tune_gemms.py [out.csv] [size=S] [batch=64] [res=224] [fresh]   (without `fresh`, new shapes are added
+usage: python tools/tune_gemms.py [out.csv] [size=S] [batch=64] [res=224] [fresh] [det]   (without `fresh`, new shapes are added
 to an existing table — e.g. `tools/tune_gemms.py medmamba_amd/tuning/gemm_gfx950.csv B 32 384`)"""
 import os, sys
 import torch
@@ -15,6 +15,8 @@ batch = int(sys.argv[3]) if len(sys.argv) > 3 else 64
 res = int(sys.argv[4]) if len(sys.argv) > 4 else 224
 if "fresh" in sys.argv[5:] and os.path.exists(out):
     os.remove(out)
+if "det" in sys.argv[5:]:        # the shapes of the deterministic weight-gradient path (cudnn.deterministic, the reference's mode)
+    torch.backends.cudnn.deterministic = True
 torch.cuda.tunable.set_max_tuning_duration(60)      # ms per candidate
 torch.cuda.tunable.set_max_tuning_iterations(50)
 enable_tuned_gemms(out, tune=True)
