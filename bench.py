@@ -43,7 +43,14 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 # below) would then not replace: 31 instead of 28 ms per step, measured.  The benchmark searches for itself, in a database of its own.
 if os.environ.get("MM_MIOPEN_BENCHMARK", "1") == "1" and "MIOPEN_USER_DB_PATH" not in os.environ:
     import tempfile
-    os.environ["MIOPEN_USER_DB_PATH"] = tempfile.mkdtemp(prefix="mm_miopen_db_")
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        # one database per launch, shared by its ranks (same parent = the launcher): rank 0 searches first (set-up passes below),
+        # the others then find its results — the same solvers on every rank instead of N independent searches with N outcomes
+        _db = os.path.join(tempfile.gettempdir(), f"mm_miopen_db_{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}")
+        os.makedirs(_db, exist_ok=True)
+        os.environ["MIOPEN_USER_DB_PATH"] = _db
+    else:
+        os.environ["MIOPEN_USER_DB_PATH"] = tempfile.mkdtemp(prefix="mm_miopen_db_")
 
 import torch
 import torch.distributed as dist
@@ -275,9 +282,21 @@ def main():
     # set-up, not warm-up: the first passes over the model run MIOpen's solver search per convolution shape (the forward and the
     # backward shapes, one stream first, then the two-stream schedule) — part of building the workload like the GEMM table above
     if torch.backends.cudnn.benchmark:
-        for _ in range(2):
-            step()
-        torch.cuda.synchronize()
+        def setup_pass():       # forward (+ backward): no collective, no optimizer step — the replicas stay identical
+            if args.mode != "train":
+                return fwd_step()
+            import contextlib
+            opt.zero_grad(set_to_none=True)
+            with (sync.no_sync() if sync is not None else (model.no_sync() if use_torch_ddp else contextlib.nullcontext())):
+                loss_fn(model(images), labels).backward()
+            opt.zero_grad(set_to_none=True)
+        for turn in range(2 if world > 1 else 1):       # N > 1: rank 0 first, then everybody else out of its database
+            if world == 1 or (rank == 0) == (turn == 0):
+                for _ in range(2):
+                    setup_pass()
+                torch.cuda.synchronize()
+            if world > 1:
+                fence()
     for _ in range(args.warmup):
         step()
     KERNEL_TIMER.enabled = True
