@@ -676,13 +676,15 @@ def test_im2col3x3_is_unfold(shape):
     assert _lib.lib().mm_im2col3x3(x.data_ptr(), cols.data_ptr(), B, C, H, W, 0, None) == -2
 
 
+@pytest.mark.parametrize("CL", [(44, 196), (43, 49)], ids=["vector", "scalar"])
 @pytest.mark.parametrize("cm", [False, True])
-def test_sum_lead_chunks_fills_the_bc_rows_of_dx_dbl(cm):
+def test_sum_lead_chunks_fills_the_bc_rows_of_dx_dbl(cm, CL):
     """mm_sum_lead_chunks: the per-workgroup partial dB / dC planes of the backward scan summed straight into rows R.. of every
     direction of d(x_dbl) (batch-major: (B, 4, C, L); channel-major: (4, C, B*L)) — same bits as mm_sum_lead on a dense copy, the dt
     rows in between untouched."""
     from medmamba_amd import _lib, selective_scan_interface as ssi
-    B, C, L, R, W = 5, 44, 196, 12, 6
+    (C, L), B, W = CL, 5, 6
+    R = C - 32              # (an odd chunk stride takes the dword path of the kernel)
     g = torch.Generator(device=DEV).manual_seed(3)
     if cm:
         dx_dbl = torch.full((4, C, B * L), 7.0, device=DEV)
