@@ -274,7 +274,8 @@ int mm_patch_merge_ln_bwd(const float* dy, const float* x, const float* gamma, c
 /* PatchEmbed2D back half (MedMamba.py:70-76: `x = self.proj(x).permute(0, 2, 3, 1)`, then LayerNorm(C)) in one pass:
  * x (batch, C, HW) contiguous NCHW conv output -> out (batch, HW, C) NHWC rows = LN(x^T) * gamma + beta, statistics mu / rstd
  * (batch * HW).  Backward: dy (batch, HW, C) -> dx (batch, C, HW) and partial sums ws[row * 2*C + (0: dgamma | C: dbeta) + c],
- * row < mm_nchw_ln_rows_ws_rows(batch, HW) (the caller sums the rows).  mm_nchw_ln_rows_supported(C): C <= 512. */
+ * row < mm_nchw_ln_rows_ws_rows(batch, HW) (the caller sums the rows).  mm_nchw_ln_rows_supported(C): C <= 512; an image (C * HW * 4 bytes)
+ * must stay below 2 GB (MM_ERR_UNSUPPORTED otherwise: the kernels address it with 32-bit byte offsets). */
 int mm_nchw_ln_rows_supported(int C);
 int mm_nchw_ln_rows_ws_rows(int batch, int HW);
 int mm_nchw_ln_rows_fwd(const float* x, const float* gamma, const float* beta, float eps, float* out, float* mu, float* rstd,

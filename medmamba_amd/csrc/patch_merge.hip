@@ -384,6 +384,7 @@ int mm_nchw_ln_rows_fwd(const float* x, const float* gamma, const float* beta, f
   if (!x || !gamma || !beta || !out || !mu || !rstd) return MM_ERR_NULL;
   if (batch <= 0 || C <= 0 || HW <= 0) return MM_ERR_SHAPE;
   if (!mm_nchw_ln_rows_supported(C)) return MM_ERR_UNSUPPORTED;
+  if ((int64_t)C * HW * 4 >= 0x7fffffffll) return MM_ERR_UNSUPPORTED;      // 32-bit byte offsets inside one image (C planes of HW)
   const int tiles_per_img = (HW + kPeT - 1) / kPeT;
   const int64_t ntiles = (int64_t)batch * tiles_per_img;
   hipStream_t s = (hipStream_t)stream;
@@ -396,6 +397,7 @@ int mm_nchw_ln_rows_bwd(const float* dy, const float* x, const float* gamma, con
   if (!dy || !x || !gamma || !mu || !rstd || !dx || !ws) return MM_ERR_NULL;
   if (batch <= 0 || C <= 0 || HW <= 0) return MM_ERR_SHAPE;
   if (!mm_nchw_ln_rows_supported(C)) return MM_ERR_UNSUPPORTED;
+  if ((int64_t)C * HW * 4 >= 0x7fffffffll) return MM_ERR_UNSUPPORTED;
   const int tiles_per_img = (HW + kPeT - 1) / kPeT;
   const int64_t ntiles = (int64_t)batch * tiles_per_img;
   hipStream_t s = (hipStream_t)stream;

@@ -182,7 +182,7 @@ class PatchEmbed2D(nn.Module):
         x = conv2d_bias(x, self.proj) if (not _has_hooks(self.proj) and ops.conv2d_bias_ok(x, self.proj)) else self.proj(x)
         n = self.norm
         if (x.is_cuda and x.dtype == torch.float32 and type(n) is nn.LayerNorm and n.elementwise_affine and n.bias is not None
-                and not _has_hooks(self) and nchw_ln_rows_supported(x.shape[1])):
+                and not _has_hooks(self) and nchw_ln_rows_supported(x.shape[1], x.shape[2] * x.shape[3])):
             return nchw_ln_rows(x, n.weight, n.bias, n.eps)          # permute + LayerNorm, one pass over HBM each way
         x = x.permute(0, 2, 3, 1)
         return x if n is None else n(x)

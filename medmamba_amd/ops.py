@@ -941,8 +941,9 @@ class NchwLNRowsFn(torch.autograd.Function):
         return dx, s[0], s[1], None
 
 
-def nchw_ln_rows_supported(C):
-    return bool(_lib.lib().mm_nchw_ln_rows_supported(int(C)))
+def nchw_ln_rows_supported(C, HW=0):
+    """C <= 512 channels; one image's C planes of HW positions within 2 GB (the kernels address them with 32-bit byte offsets)."""
+    return bool(_lib.lib().mm_nchw_ln_rows_supported(int(C))) and int(C) * int(HW) * 4 < 0x7fffffff
 
 
 def nchw_ln_rows(x, gamma, beta, eps):
