@@ -21,7 +21,10 @@ Extra objects on the line:
                  of every forward scan call in the timed steps / their hipEvent-measured duration, vs 8 TB/s.
                  In the timed steps the conv branch of every block runs beside the scan on a second HIP stream, so
                  `achieved` is the kernel's rate while sharing the GPU; `achieved_alone` / `frac_alone` repeat the
-                 measurement in 3 extra untimed steps with that overlap switched off (N=1 only).
+                 measurement in 3 extra untimed steps with that overlap switched off (N=1 only).  `frac` / `frac_alone`
+                 are the raw event times; an event pair adds its own ~5 us to every bracketed launch (measured live as
+                 `event_bracket_us`, checked against rocprofv3's kernel durations in profiles/r4_event_bracket_vs_kernel_trace.txt):
+                 `frac_net` / `frac_alone_net` have it removed and are what a kernel trace of the same launches shows.
   roofline_bwd — same for the backward scan kernel.
   cpu_baseline — the CPU restatement of the reference path (oracle/: torch-CPU glue + C selective_scan_ref)
                  timed on this box's host cores on a bounded sample (rank 0, N=1 only).
@@ -324,6 +327,18 @@ def main():
         KERNEL_TIMER.enabled = False
         _modules._TWO_STREAMS = two
         ks_iso = KERNEL_TIMER.summary()
+    # what the event pair itself adds to a bracketed launch: the empty bracket behind a running kernel (profiles/
+    # r4_event_bracket_vs_kernel_trace.txt: event time - kernel-trace duration = the empty bracket, 5.0-5.2 us, whatever the kernel)
+    bracket_us = None
+    if rank == 0:
+        probe = torch.zeros(1 << 20, device=dev)
+        pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(60)]
+        for s_, e_ in pairs:
+            probe.add_(1.0)
+            s_.record()
+            e_.record()
+        torch.cuda.synchronize()
+        bracket_us = 1e3 * sorted(s_.elapsed_time(e_) for s_, e_ in pairs)[len(pairs) // 2]
     dist_info = None
     if world > 1:
         # every rank's own wall time of the timed region and the window its gradient all-reduces were in flight (device events of
@@ -391,10 +406,16 @@ def main():
                  "algorithmic_MB_per_call": round(d["bytes"] / d["calls"] / 1e6, 2)}
             floor_ms = d["state_steps"] / 64.0 * VALU_FLOOR_NS_PER_WAVE_STEP[tag] / N_SIMD * 1e-6
             r["valu_floor_frac"] = round(floor_ms / d["ms"], 4)
+            net = lambda k: k["bytes"] / (k["ms"] - k["calls"] * bracket_us * 1e-3) / 1e6 / HBM_PEAK_GBS      # the event pair's own time removed
+            if bracket_us is not None and 0 < bracket_us < 20:
+                r["event_bracket_us"] = round(bracket_us, 2)
+                r["frac_net"] = round(net(d), 4)
             i = ks_iso.get(tag)
             if i and i["ms"] > 0:       # same kernel, same shapes, nothing else on the GPU (see above)
                 r["achieved_alone"] = round(i["bytes"] / i["ms"] / 1e6, 1)
                 r["frac_alone"] = round(r["achieved_alone"] / HBM_PEAK_GBS, 4)
+                if "frac_net" in r:
+                    r["frac_alone_net"] = round(net(i), 4)
                 r["valu_floor_frac_alone"] = round(i["state_steps"] / 64.0 * VALU_FLOOR_NS_PER_WAVE_STEP[tag] / N_SIMD * 1e-6 / i["ms"], 4)
             return r
 
