@@ -44,7 +44,8 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 # MIOpen keeps what its solver searches found in a per-user database and later processes inherit it — including the quick-search
 # picks of whatever ran before on the box (a test suite, a profiling run), which this process's own full search (cudnn.benchmark,
 # below) would then not replace: 31 instead of 28 ms per step, measured.  The benchmark searches for itself, in a database of its own.
-if os.environ.get("MM_MIOPEN_BENCHMARK", "1") == "1" and "MIOPEN_USER_DB_PATH" not in os.environ:
+_PRIVATE_MIOPEN_DB = os.environ.get("MM_MIOPEN_BENCHMARK", "1") == "1" and "MIOPEN_USER_DB_PATH" not in os.environ
+if _PRIVATE_MIOPEN_DB:
     import tempfile
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:
         # one database per launch, shared by its ranks (same parent = the launcher): rank 0 searches first (set-up passes below),
@@ -62,6 +63,14 @@ import torch.nn as nn
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+
+# ... and that database starts from the recorded search of medmamba_amd/tuning/miopen_gfx950/ (the conv-side counterpart of the GEMM
+# table: same solvers on every box, no 70 s search for the recorded shapes; MIOpen ignores it when its build differs and searches as
+# before; MM_MIOPEN_SEED_DB=0 starts from an empty database).  Before the first convolution: MIOpen reads the directory once.
+MIOPEN_DB_SEEDED = 0
+if _PRIVATE_MIOPEN_DB and os.environ.get("MM_MIOPEN_SEED_DB", "1") == "1":
+    from medmamba_amd.tuning import seed_miopen_db
+    MIOPEN_DB_SEEDED = seed_miopen_db(os.environ["MIOPEN_USER_DB_PATH"])
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md §Chip-level parameters)
 # Secondary ceiling of the scan kernels ("fp32 VALU / v_exp_f32 issue"): the irreducible VALU work per state-step —
@@ -440,6 +449,9 @@ def main():
         if dist_info is not None:
             out["distributed"] = dist_info
         out.update(extras)
+        out["miopen_find_db"] = (f"private, seeded with {MIOPEN_DB_SEEDED} recorded files of medmamba_amd/tuning/miopen_gfx950 (MIOpen searches only "
+                                 "the shapes they do not hold)" if MIOPEN_DB_SEEDED else
+                                 ("private, searched by this process" if _PRIVATE_MIOPEN_DB else "MIOPEN_USER_DB_PATH of the caller"))
         if out["roofline"] is not None and out["roofline"].get("traffic") is not None:
             out["roofline"]["traffic_source"] = "profiles/scan_traffic.json @ " + str(traffic.get("measured_at_commit", "unrecorded"))
         if out["roofline_bwd"] is None:

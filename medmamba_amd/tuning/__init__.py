@@ -27,3 +27,35 @@ def enable_tuned_gemms(path=None, tune=False):
     from .. import blas
     blas.load_table(path)          # the same record drives the direct rocBLAS route of the package's own GEMM call sites
     return path
+
+
+# ---- MIOpen's solver picks for the conv branch's dense convolutions ------------------------------------------------------------
+# MIOpen keeps what its solver search found in a per-user "find database" (plain text, one line per convolution problem, named
+# after the GPU and the MIOpen build) and looks a problem up there before it measures anything.  Its search times every solver
+# once, so near ties (Winograd vs implicit GEMM at the 14x14 and 7x7 stages) fall differently from box to box: 27.8 vs 28.7 ms per
+# step of S / 64, and ~70 s of searching per process.  `miopen_gfx950/` is the database of a search on an MI355X
+# with this image's MIOpen build for the shapes of BASELINE's single-GPU configurations — the conv-side counterpart of
+# gemm_gfx950.csv.  MIOpen ignores files recorded by another build (the build id is part of the file name) and searches as before.
+MIOPEN_DB_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "miopen_gfx950")
+
+
+def seed_miopen_db(dst):
+    """Copy the recorded find / perf database files into the directory `dst` (a MIOPEN_USER_DB_PATH) unless a file of that name is
+    already there.  Safe when several ranks seed one directory at once (each file arrives by an atomic rename).  Returns the
+    number of files written.  Call before the first convolution of the process (MIOpen reads the directory once)."""
+    if not os.path.isdir(MIOPEN_DB_DIR):
+        return 0
+    os.makedirs(dst, exist_ok=True)
+    n = 0
+    for f in sorted(os.listdir(MIOPEN_DB_DIR)):
+        if not f.endswith(".txt"):
+            continue
+        out = os.path.join(dst, f)
+        if os.path.exists(out):
+            continue
+        tmp = f"{out}.{os.getpid()}.tmp"
+        with open(os.path.join(MIOPEN_DB_DIR, f), "rb") as src, open(tmp, "wb") as o:
+            o.write(src.read())
+        os.replace(tmp, out)
+        n += 1
+    return n
