@@ -53,9 +53,11 @@ def seed_miopen_db(dst):
         out = os.path.join(dst, f)
         if os.path.exists(out):
             continue
-        tmp = f"{out}.{os.getpid()}.tmp"
-        with open(os.path.join(MIOPEN_DB_DIR, f), "rb") as src, open(tmp, "wb") as o:
+        import tempfile
+        fd, tmp = tempfile.mkstemp(dir=dst, suffix=".tmp")      # a name of its own per caller (process or thread)
+        with open(os.path.join(MIOPEN_DB_DIR, f), "rb") as src, os.fdopen(fd, "wb") as o:
             o.write(src.read())
+        os.chmod(tmp, 0o644)
         os.replace(tmp, out)
         n += 1
     return n

@@ -121,3 +121,42 @@ def test_cli_flags_match_the_reference(monkeypatch):
                           "--seed", "1", "--num_classes", "4", "--batch_size", "2", "--epochs", "5", "--lr", "0.01"])
     assert (a.medmb_size, a.resume, a.use_early_stopping, a.augmentation, a.attn_drop_rate, a.patience) == ("B", "c.pth", True, True, 0.1, 3)
     assert train.parse_args([]).medmb_size == "T" and train.parse_args([]).seed == 42 and train.parse_args([]).patience == 25
+
+
+def test_recorded_miopen_database_seeds_a_directory_once(tmp_path):
+    """tuning.seed_miopen_db (what bench.py starts its private MIOpen database from): every recorded file arrives whole under its own
+    name (MIOpen matches GPU and build by file name), nothing is overwritten, a second call — or a second rank — is a no-op, and
+    every line of the find database has the `problem=solver:time,workspace,algorithm;...` shape MIOpen parses."""
+    import threading
+    from medmamba_amd import tuning
+    names = sorted(f for f in os.listdir(tuning.MIOPEN_DB_DIR) if f.endswith(".txt"))
+    assert any(f.endswith(".ufdb.txt") for f in names) and any(f.endswith(".udb.txt") for f in names)
+    assert all(f.startswith("gfx950") for f in names)
+    d = str(tmp_path / "db")
+    counts = []
+    ts = [threading.Thread(target=lambda: counts.append(tuning.seed_miopen_db(d))) for _ in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert sorted(os.listdir(d)) == names and sum(counts) >= len(names)
+    for f in names:
+        assert open(os.path.join(d, f), "rb").read() == open(os.path.join(tuning.MIOPEN_DB_DIR, f), "rb").read()
+    assert tuning.seed_miopen_db(d) == 0
+    mine = os.path.join(d, names[0])
+    open(mine, "w").write("kept")
+    assert tuning.seed_miopen_db(d) == 0 and open(mine).read() == "kept"
+    ufdb = [f for f in names if f.endswith(".ufdb.txt")][0]
+    keys = set()
+    for line in open(os.path.join(tuning.MIOPEN_DB_DIR, ufdb)):
+        key, val = line.rstrip("\n").split("=", 1)
+        assert key.endswith(("-F", "-B", "-W")) and "NCHW-FP32" in key
+        for ent in val.split(";"):
+            solver, rec = ent.split(":")
+            t_ms, ws, algo = rec.split(",")
+            assert float(t_ms) > 0 and int(ws) >= 0 and algo.startswith("miopenConvolution")
+        keys.add(key)
+    # the dense 3x3 convolutions of S at 64 images (BASELINE config 3), forward / data / weight gradient at all four stages
+    for c, hw in ((48, 56), (96, 28), (192, 14), (384, 7)):
+        for d_ in "FBW":
+            assert f"{c}-{hw}-{hw}-3x3-{c}-{hw}-{hw}-64-1x1-1x1-1x1-0-NCHW-FP32-{d_}" in keys
