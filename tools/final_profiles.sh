@@ -8,6 +8,8 @@ export TMPDIR=/tmp
 # one MIOpen find-db for the whole set: the first bench process searches (cudnn.benchmark, ~70 s), every later process — profiled
 # or not — runs the same solvers (bench.py keeps a database of its own per process otherwise)
 export MIOPEN_USER_DB_PATH=/tmp/mm_final_db_$tag; mkdir -p $MIOPEN_USER_DB_PATH
+# ... which starts, like bench.py's own private database, from the recorded search (medmamba_amd/tuning/miopen_gfx950)
+python3 -c "import sys; sys.path.insert(0, '.'); from medmamba_amd.tuning import seed_miopen_db; print('seeded', seed_miopen_db('$MIOPEN_USER_DB_PATH'))"
 run() { name=$1; secs=$2; shift 2; echo "== $name"; timeout -k 10 $secs "$@" > $out/$name.log 2>&1; rc=$?; echo "== $name rc=$rc"; if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then exit $rc; fi; }
 run bench_config3 600 python3 bench.py
 tail -1 $out/bench_config3.log > $out/bench_config3.json
