@@ -290,14 +290,15 @@ std::vector<Tensor> ss2d_fwd(const Tensor& x, const Tensor& in_w, const Tensor& 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// backward.  Returns {dx (B, L, d_model), d in_w, d conv_w, d conv_b, d x_proj_w, d dt_w, d dt_b, d A_logs, d Ds, d ln_w, d ln_b,
-// d out_w}
+// backward, in two halves: what d(input) waits for, and the parameter gradients that nothing on the way to d(input) needs (the five
+// weight-gradient GEMMs and the un-packing launch).  ss2d_bwd issues both on one stream.  Same kernels, same operands, same bits.
+// ss2d_bwd_data returns {dx (B, L, d_model), dxz, ddelta, dx_dbl, parts, ws, wsc} — dx and what the parameter half reads.
 // ---------------------------------------------------------------------------------------------------------------------
-std::vector<Tensor> ss2d_bwd(const Tensor& dout_, const Tensor& x, const Tensor& in_w, const Tensor& conv_w,
-                             const c10::optional<Tensor>& conv_b_, const Tensor& ln_w, const Tensor& ln_b, const Tensor& out_w,
-                             const Tensor& xz, const Tensor& u2, const Tensor& x_dbl, const Tensor& delta, const Tensor& P,
-                             const Tensor& x_chk, const Tensor& m, const Tensor& mu, const Tensor& rstd, const Tensor& y, int64_t H,
-                             int64_t W, bool cm, bool pack_fold, int64_t variant, int64_t stream_, int64_t ev0, int64_t ev1) {
+std::vector<Tensor> ss2d_bwd_data(const Tensor& dout_, const Tensor& x, const Tensor& in_w, const Tensor& conv_w,
+                                  const c10::optional<Tensor>& conv_b_, const Tensor& ln_w, const Tensor& ln_b, const Tensor& out_w,
+                                  const Tensor& xz, const Tensor& u2, const Tensor& x_dbl, const Tensor& delta, const Tensor& P,
+                                  const Tensor& x_chk, const Tensor& m, const Tensor& mu, const Tensor& rstd, int64_t H, int64_t W, bool cm,
+                                  int64_t variant, int64_t stream_, int64_t ev0, int64_t ev1) {
   void* stream = reinterpret_cast<void*>(stream_);
   const Tensor conv_b = conv_b_.has_value() ? *conv_b_ : Tensor();
   const int64_t Bsz = x.size(0), L = x.size(1), dm = x.size(2);
@@ -307,19 +308,16 @@ std::vector<Tensor> ss2d_bwd(const Tensor& dout_, const Tensor& x, const Tensor&
   const Seg s = segments(P, D, C, R, N);
   const Tensor x_cf = xz.narrow(1, 0, D), z_cf = xz.narrow(1, D, D);
   // out_proj backward
-  Tensor dy, d_out_w;
+  Tensor dy;
   if (cm && Bsz > 1 && is_cm(dout_)) {
     const Tensor g2 = cm2d(dout_);                                                        // (d_model, Q)
     dy = at::empty({D, Q}, o);
     gemm_out(dy, out_w.t(), g2, stream);
     dy = dy.view({D, Bsz, L}).permute({1, 0, 2});
-    d_out_w = at::empty({out_w.size(0), D}, o);
-    gemm_out(d_out_w, g2, cm2d(y).t(), stream);
   } else {
     const Tensor g = rows(dout_);
     dy = at::empty({Bsz, D, L}, o);
     gemm_out(dy, out_w.t(), g, stream);
-    d_out_w = sum_lead(gemm_new(g, rows(y).transpose(1, 2), stream), stream);
   }
   // out_norm + gate backward, its plane transpose for the column-major directions
   Tensor dout2 = planes(Bsz, 2 * D, L, o, cm);            // channel block 0: dm, block 1: its plane transpose
@@ -334,9 +332,6 @@ std::vector<Tensor> ss2d_bwd(const Tensor& dout_, const Tensor& x, const Tensor&
     check(mm_plane_transpose(fp(dout2), dout2.stride(0), dout2.stride(1), fpm(d1), d1.stride(0), d1.stride(1), (int)Bsz, (int)D, (int)H,
                              (int)W, stream), "mm_plane_transpose");
   }
-  // packed parameter gradients: the GEMMs write the two weight segments, the scan kernel per-batch-item partials of A / D / bias
-  Tensor dP = at::empty_like(P);
-  const Seg ds = segments(dP, D, C, R, N);
   const int64_t S = mm_ss2d_pack_parts_size((int)D, (int)C, (int)R, (int)N);
   Tensor parts = at::empty({Bsz, S}, o);
   Tensor dx_dbl, xb, dxb;
@@ -383,27 +378,19 @@ std::vector<Tensor> ss2d_bwd(const Tensor& dout_, const Tensor& x, const Tensor&
   Tensor du2;
   if (cm) {
     const Tensor dd = ddelta.permute({1, 0, 2}).reshape({4, D, Q});                        // views of (4D, B, L) storage
-    Tensor dWdt = ds.Wdt, dxr = dx_dbl.narrow(1, 0, R);
-    gemm_out(dWdt, dd, x_dbl.narrow(1, 0, R).transpose(1, 2), stream);                     // (4, D, R)
+    Tensor dxr = dx_dbl.narrow(1, 0, R);
     gemm_out(dxr, s.Wdt.transpose(1, 2), dd, stream);                                     // dt rows of d(x_dbl), in place
     const Tensor dx2 = dx_dbl.view({2, 2 * C, Q});
     Tensor du2m = at::empty({2, D, Q}, o);
     gemm_out(du2m, s.Wx.view({2, 2 * C, D}).transpose(1, 2), dx2, stream);                 // Wx^T d(x_dbl); pairs added later
-    Tensor dWx = ds.Wx.view({2, 2 * C, D});
-    gemm_out(dWx, dx2, cm2d(u2).view({2, D, Q}).transpose(1, 2), stream);
     du2 = du2m.view({2 * D, Bsz, L}).permute({1, 0, 2});
   } else {
     const Tensor dd = ddelta.view({Bsz, 4, D, L});
-    const Tensor xr = x_dbl.narrow(2, 0, R);
-    Tensor dWdt = ds.Wdt;
-    sum_lead(at::matmul(dd, xr.transpose(-1, -2)), stream, dWdt);                           // (4, D, R)
     dx_dbl.narrow(2, 0, R).copy_(at::matmul(s.Wdt.transpose(-1, -2).unsqueeze(0), dd));    // dt rows of d(x_dbl)
     const Tensor Wx2 = s.Wx.view({2, 2 * C, D});
     const Tensor dxd2 = dx_dbl.view({Bsz, 2, 2 * C, L});
     const Tensor WxT = Wx2.transpose(1, 2).unsqueeze(0).expand({Bsz, -1, -1, -1}).reshape({Bsz * 2, D, 2 * C});
     du2 = at::bmm(WxT, dxd2.reshape({Bsz * 2, 2 * C, L}));                                 // Wx^T d(x_dbl); pairs added later
-    Tensor dWx = ds.Wx.view({2, 2 * C, D});
-    sum_lead(at::matmul(dxd2, u2.view({Bsz, 2, D, L}).transpose(-1, -2)), stream, dWx);
     du2 = du2.view({Bsz, 2 * D, L});
   }
   // d(u2) = projection part + the scan's two direction pairs, summed inside the depthwise conv's backward kernel
@@ -413,6 +400,53 @@ std::vector<Tensor> ss2d_bwd(const Tensor& dout_, const Tensor& x, const Tensor&
   check(mm_dwconv_silu_cross_bwd(fp(du2), du2.stride(0), du2.stride(1), fp(du4), du4.stride(0), du4.stride(1), fp(x_cf), x_cf.stride(0),
                                  x_cf.stride(1), fp(conv_w), fp(conv_b), fpm(dxc), dxc.stride(0), dxc.stride(1), fpm(wsc), (int)Bsz, (int)D,
                                  (int)H, (int)W, stream), "mm_dwconv_silu_cross_bwd");
+  // in_proj backward (data)
+  Tensor dx;
+  if (cm && is_cm(dxz)) {
+    dx = at::empty({Q, dm}, o);
+    gemm_out(dx, cm2d(dxz).t(), in_w, stream);
+    dx = dx.view({Bsz, L, dm});
+  } else {
+    dx = at::empty({Bsz, L, dm}, o);
+    gemm_out(dx, dxz.transpose(1, 2), in_w, stream);
+  }
+  return {dx, dxz, ddelta, dx_dbl, parts, ws, wsc};
+}
+
+// The parameter half.  Returns {d in_w, d conv_w, d conv_b, d x_proj_w, d dt_w, d dt_b, d A_logs, d Ds, d ln_w, d ln_b, d out_w}.
+std::vector<Tensor> ss2d_bwd_params(const Tensor& dout_, const Tensor& x, const Tensor& in_w, const c10::optional<Tensor>& conv_b_,
+                                    const Tensor& out_w, const Tensor& u2, const Tensor& x_dbl, const Tensor& P, const Tensor& y,
+                                    const Tensor& dxz, const Tensor& ddelta, const Tensor& dx_dbl, const Tensor& parts, const Tensor& ws,
+                                    const Tensor& wsc, int64_t H, int64_t W, bool cm, bool pack_fold, int64_t stream_) {
+  void* stream = reinterpret_cast<void*>(stream_);
+  const Tensor conv_b = conv_b_.has_value() ? *conv_b_ : Tensor();
+  const int64_t Bsz = x.size(0), L = x.size(1), dm = x.size(2);
+  const int64_t D = in_w.size(0) / 2, N = 16;
+  const int64_t C = cm ? x_dbl.size(1) : x_dbl.size(2), R = C - 2 * N, Q = Bsz * L;
+  const auto o = x.options();
+  Tensor d_out_w;
+  if (cm && Bsz > 1 && is_cm(dout_)) {
+    d_out_w = at::empty({out_w.size(0), D}, o);
+    gemm_out(d_out_w, cm2d(dout_), cm2d(y).t(), stream);
+  } else {
+    d_out_w = sum_lead(gemm_new(rows(dout_), rows(y).transpose(1, 2), stream), stream);
+  }
+  // packed parameter gradients: the GEMMs write the two weight segments, the scan kernel left per-batch-item partials of A / D / bias
+  Tensor dP = at::empty_like(P);
+  const Seg ds = segments(dP, D, C, R, N);
+  if (cm) {
+    const Tensor dd = ddelta.permute({1, 0, 2}).reshape({4, D, Q});                        // views of (4D, B, L) storage
+    Tensor dWdt = ds.Wdt;
+    gemm_out(dWdt, dd, x_dbl.narrow(1, 0, R).transpose(1, 2), stream);                     // (4, D, R)
+    Tensor dWx = ds.Wx.view({2, 2 * C, D});
+    gemm_out(dWx, dx_dbl.view({2, 2 * C, Q}), cm2d(u2).view({2, D, Q}).transpose(1, 2), stream);
+  } else {
+    Tensor dWdt = ds.Wdt;
+    sum_lead(at::matmul(ddelta.view({Bsz, 4, D, L}), x_dbl.narrow(2, 0, R).transpose(-1, -2)), stream, dWdt);   // (4, D, R)
+    Tensor dWx = ds.Wx.view({2, 2 * C, D});
+    sum_lead(at::matmul(dx_dbl.view({Bsz, 2, 2 * C, L}), u2.view({Bsz, 2, D, L}).transpose(-1, -2)), stream, dWx);
+  }
+  const int strips = mm_dwconv_silu_cross_strips((int)H, (int)W);
   // one launch: packed gradients back to the module's layouts, ln_gate's partial rows, the depthwise conv's partial sums
   const int64_t npk = P.numel();
   Tensor G = at::empty({npk + 2 * D + 10 * D}, o);
@@ -428,20 +462,24 @@ std::vector<Tensor> ss2d_bwd(const Tensor& dout_, const Tensor& x, const Tensor&
   }
   Tensor dcw = dw_out.narrow(0, 0, 9 * D).view({D, 1, 3, 3});
   Tensor dcb = conv_b.defined() ? dw_out.narrow(0, 9 * D, D) : Tensor();
-  // in_proj backward: one GEMM per product over all 2D rows
-  Tensor dx, d_in_w = at::empty_like(in_w);
-  if (cm && is_cm(dxz)) {
-    const Tensor g2 = cm2d(dxz), x2 = x.view({Q, dm});
-    dx = at::empty({Q, dm}, o);
-    gemm_out(dx, g2.t(), in_w, stream);
-    dx = dx.view({Bsz, L, dm});
-    gemm_out(d_in_w, g2, x2, stream);
-  } else {
-    dx = at::empty({Bsz, L, dm}, o);
-    gemm_out(dx, dxz.transpose(1, 2), in_w, stream);
-    sum_lead(gemm_new(dxz, x, stream), stream, d_in_w);
-  }
-  return {dx, d_in_w, dcw, dcb, gs.Wx, gs.Wdt, gs.bias.view({4, D}), gs.A, gs.Dp, ln_out.narrow(0, 0, D), ln_out.narrow(0, D, D), d_out_w};
+  Tensor d_in_w = at::empty_like(in_w);
+  if (cm && is_cm(dxz)) gemm_out(d_in_w, cm2d(dxz), x.view({Q, dm}), stream);
+  else sum_lead(gemm_new(dxz, x, stream), stream, d_in_w);
+  return {d_in_w, dcw, dcb, gs.Wx, gs.Wdt, gs.bias.view({4, D}), gs.A, gs.Dp, ln_out.narrow(0, 0, D), ln_out.narrow(0, D, D), d_out_w};
+}
+
+// Both halves on one stream.  Returns {dx, d in_w, d conv_w, d conv_b, d x_proj_w, d dt_w, d dt_b, d A_logs, d Ds, d ln_w, d ln_b, d out_w}
+std::vector<Tensor> ss2d_bwd(const Tensor& dout_, const Tensor& x, const Tensor& in_w, const Tensor& conv_w,
+                             const c10::optional<Tensor>& conv_b_, const Tensor& ln_w, const Tensor& ln_b, const Tensor& out_w,
+                             const Tensor& xz, const Tensor& u2, const Tensor& x_dbl, const Tensor& delta, const Tensor& P,
+                             const Tensor& x_chk, const Tensor& m, const Tensor& mu, const Tensor& rstd, const Tensor& y, int64_t H,
+                             int64_t W, bool cm, bool pack_fold, int64_t variant, int64_t stream_, int64_t ev0, int64_t ev1) {
+  const std::vector<Tensor> d = ss2d_bwd_data(dout_, x, in_w, conv_w, conv_b_, ln_w, ln_b, out_w, xz, u2, x_dbl, delta, P, x_chk, m, mu,
+                                              rstd, H, W, cm, variant, stream_, ev0, ev1);
+  std::vector<Tensor> g = ss2d_bwd_params(dout_, x, in_w, conv_b_, out_w, u2, x_dbl, P, y, d[1], d[2], d[3], d[4], d[5], d[6], H, W, cm,
+                                          pack_fold, stream_);
+  g.insert(g.begin(), d[0]);
+  return g;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -562,6 +600,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, mod) {
   mod.doc() = "medmamba_amd: C++ sequencing of the SS2D branch over the C ABI of libmedmamba_hip.so";
   mod.def("ss2d_fwd", &ss2d_fwd);
   mod.def("ss2d_bwd", &ss2d_bwd);
+  mod.def("ss2d_bwd_data", &ss2d_bwd_data);
+  mod.def("ss2d_bwd_params", &ss2d_bwd_params);
   mod.def("set_gemm_table", &set_gemm_table);
   mod.def("abi_version", []() { return mm_abi_version(); });
 }

@@ -157,6 +157,8 @@ class GradSync:
             side = modules._side_stream(grads[0].device) if modules._TWO_STREAMS else None
             if side is not None:
                 torch.cuda.current_stream(grads[0].device).wait_stream(side)
+            from . import ops
+            ops.join_param_stream(grads[0].device)      # (MM_PARAM_STREAM experiment: the SS2D parameter gradients' own stream)
         flat = torch._utils._flatten_dense_tensors(grads)
         ev = None
         if self.timing and flat.is_cuda:

@@ -572,6 +572,44 @@ class SS2DCoreFn(torch.autograd.Function):
         return (du2, dcw, dcb, gWx, gWdt, gb.view(4, D), gA, gD, dz, ln_out[:D], ln_out[D:], None, None, None, None, None)
 
 
+# ---- EXPERIMENT, off by default: the SS2D backward's parameter half on a third stream -----------------------------
+# Nothing on the way to d(input) waits for the five weight-gradient GEMMs and the un-packing launch of a block.  MM_PARAM_STREAM=1
+# issues them (ss2d_bwd_params) on a third stream behind an event recorded after the data half (ss2d_bwd_data); the stream of the
+# backward pass waits for that stream ONCE, in an end-of-backward callback of the autograd engine.  Measured: 27.06 instead of
+# 27.66-27.79 ms per step of S / 64 — and, with steps queued back to back, the GPU STOPS in roughly two runs of bench.py out of
+# five, whatever GPU_MAX_HW_QUEUES is (tools/param_stream_ab.py, tools/param_stream_soak.sh).  Not the stream / event / allocator
+# steps below (the same steps around a trivial kernel: 7 runs of 7 clean), not the recorded GEMM solutions (rocBLAS's own picks stop
+# it too), the channel-major blocks alone suffice: library GEMMs on a third busy queue.  Do not enable outside an experiment.
+_PARAM_STREAM_MODE = os.environ.get("MM_PARAM_STREAM", "0")
+_PARAM_STREAMS = {}            # device -> [stream, join scheduled?, used since the last join?]
+
+
+def _param_state(device):
+    st = _PARAM_STREAMS.get(device)
+    if st is None:
+        st = _PARAM_STREAMS[device] = [torch.cuda.Stream(device=device), False, False]
+    return st
+
+
+def join_param_stream(device=None):
+    """Make the current stream wait for the parameter-gradient work queued so far (no-op when there is none)."""
+    for dev, st in _PARAM_STREAMS.items():
+        if (device is None or dev == torch.device(device)) and st[2]:
+            torch.cuda.current_stream(dev).wait_stream(st[0])
+            st[2] = False
+
+
+def _join_at_end_of_backward(device):
+    st = _param_state(device)
+
+    def cb():
+        st[1] = False
+        join_param_stream(device)
+    if not st[1]:
+        st[1] = True
+        torch.autograd.Variable._execution_engine.queue_callback(cb)
+
+
 class SS2DBranchFn(torch.autograd.Function):
     """The whole SS2D branch (MedMamba.py:288-305 without dropout) as one autograd node whose forward and backward are ONE call
     each into the C++ sequencing layer (csrc_host/ss2d_host.cpp): x (B, L, d_model) rows -> (B, d_model, L) planes.  Same
@@ -610,8 +648,29 @@ class SS2DBranchFn(torch.autograd.Function):
         with _lib.device_guard(x.device):
             bt = BRANCH_TIMER.start()
             ev0, ev1 = KERNEL_TIMER.pair("scan_bwd", scan_bytes_bwd(Bsz, 4 * D, L, 16, 4), Bsz * 4 * D * L * 16)
-            g = _host.module().ss2d_bwd(dout, x, in_w, conv_w, conv_b, ln_w, ln_b, out_w, xz, u2, x_dbl, delta, P, x_chk, m, mu, rstd, y,
-                                        H, W, cm, _PACK_FOLD, _BWD_VARIANT, _stream(), ev0, ev1)
+            if _PARAM_STREAM_MODE == "0":
+                g = _host.module().ss2d_bwd(dout, x, in_w, conv_w, conv_b, ln_w, ln_b, out_w, xz, u2, x_dbl, delta, P, x_chk, m, mu, rstd, y,
+                                            H, W, cm, _PACK_FOLD, _BWD_VARIANT, _stream(), ev0, ev1)
+            else:
+                mod = _host.module()
+                d = mod.ss2d_bwd_data(dout, x, in_w, conv_w, conv_b, ln_w, ln_b, out_w, xz, u2, x_dbl, delta, P, x_chk, m, mu, rstd,
+                                      H, W, cm, _BWD_VARIANT, _stream(), ev0, ev1)
+                st = _param_state(x.device)
+                ps = st[0]
+                main = torch.cuda.current_stream(x.device)
+                ev = torch.cuda.Event()     # a new event per call (re-recording one with a wait still queued is asking for trouble)
+                ev.record(main)
+                with torch.cuda.stream(ps):
+                    ps.wait_event(ev)
+                    gp = mod.ss2d_bwd_params(dout, x, in_w, conv_b, out_w, u2, x_dbl, P, y, *d[1:], H, W, cm, _PACK_FOLD, _stream())
+                for t in (dout, x, u2, x_dbl, P, y, *d[1:]):   # freed by the engine / this frame while `ps` may still read them
+                    t.record_stream(ps)
+                for t in gp:                # allocated under `ps`, consumed on the main stream (optimizer, all-reduce)
+                    if t is not None:
+                        t.record_stream(main)
+                st[2] = True
+                _join_at_end_of_backward(x.device)
+                g = [d[0], *gp]
             BRANCH_TIMER.stop("ss2d_bwd", bt)
         dx, d_in, dcw, dcb, gWx, gWdt, gb, gA, gD, dlw, dlb, d_out = g
         return dx, d_in, dcw, dcb, gWx, gWdt, gb, gA, gD, dlw, dlb, d_out, None, None, None, None, None
