@@ -579,7 +579,8 @@ class SS2DCoreFn(torch.autograd.Function):
 # 27.66-27.79 ms per step of S / 64 — and, with steps queued back to back, the GPU STOPS in roughly two runs of bench.py out of
 # five, whatever GPU_MAX_HW_QUEUES is (tools/param_stream_ab.py, tools/param_stream_soak.sh).  Not the stream / event / allocator
 # steps below (the same steps around a trivial kernel: 7 runs of 7 clean), not the recorded GEMM solutions (rocBLAS's own picks stop
-# it too), the channel-major blocks alone suffice: library GEMMs on a third busy queue.  Do not enable outside an experiment.
+# it too, so does ATen's route), the channel-major blocks alone suffice, element-wise work or square GEMMs there never stop it: the
+# library's large-K (split-K) GEMMs on a third busy queue.  Do not enable outside an experiment.
 _PARAM_STREAM_MODE = os.environ.get("MM_PARAM_STREAM", "0")
 _PARAM_STREAMS = {}            # device -> [stream, join scheduled?, used since the last join?]
 
