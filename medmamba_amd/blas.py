@@ -97,6 +97,18 @@ def load_table(path):
     from . import _host
     if _host.module() is not None:          # the C++ sequencing layer issues its GEMMs the same way (csrc_host gemm_out)
         _host.module().set_gemm_table([(("B" if batched else "N") + key, sol) for (batched, key), sol in _TABLE.items()])
+        # rocBLAS-only winners (tools/tune_param_gemms.py) for the parameter half on its own stream (ops.py, MM_PARAM_STREAM): same
+        # validators, read only next to the default table
+        rb_path = os.path.join(os.path.dirname(path), "gemm_gfx950_rocblas.csv")
+        rb = []
+        if os.path.exists(rb_path):
+            rrows = list(csv.reader(open(rb_path)))
+            rrec = {r[1]: r[2] for r in rrows if len(r) >= 3 and r[0] == "Validator"}
+            if rrec.get("ROCBLAS_VERSION") == have and (arch is None or rrec.get("GCN_ARCH_NAME") in (None, arch)):
+                for r in rrows:
+                    if len(r) >= 3 and r[2].startswith("Gemm_Rocblas_") and r[0].startswith(("GemmStridedBatchedTunableOp_float_", "GemmTunableOp_float_")):
+                        rb.append((("B" if r[0].startswith("GemmStridedBatched") else "N") + r[1], int(r[2][len("Gemm_Rocblas_"):])))
+        _host.module().set_gemm_table_rb(rb)
     return len(_TABLE)
 
 

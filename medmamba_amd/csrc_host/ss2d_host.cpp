@@ -59,6 +59,8 @@ inline Tensor rows(const Tensor& t) { return t.stride(-1) == 1 ? t : t.contiguou
 std::unordered_map<std::string, int32_t> g_gemm_table;      // filled once by blas.load_table (set_gemm_table); afterwards only a value
                                                              // may change, to kDeclined (a solution the library rejected)
 constexpr int32_t kDeclined = INT32_MIN;
+bool g_rocblas_only = false;      // set around the parameter half when it runs on its own stream (ops.py, MM_PARAM_STREAM)
+std::unordered_map<std::string, int32_t> g_gemm_table_rb;   // rocBLAS-only winners for shapes whose overall winner is a hipBLASLt kernel
 
 inline bool col_operand(const Tensor& t, char& op, int64_t& ld) {
   const int64_t s0 = t.stride(-2), s1 = t.stride(-1);
@@ -69,7 +71,34 @@ inline bool col_operand(const Tensor& t, char& op, int64_t& ld) {
 
 // out = a @ b; a (m, k) or (B, m, k), b (k, n) or (B, k, n), out (m, n) or (B, m, n): a 2-D operand of a 3-D product is shared
 inline void gemm_out(Tensor& out, const Tensor& a, const Tensor& b, void* stream) {
-  if (!g_gemm_table.empty() && out.stride(-1) == 1) {
+  if (g_rocblas_only && out.stride(-1) == 1) {
+    // the parameter half on its own stream (MM_PARAM_STREAM): rocBLAS kernels only — the rocBLAS-only record first, the main record if
+    // its winner is a rocBLAS solution, rocBLAS's own pick (solution 0) otherwise
+    char opa, opb;
+    int64_t lda, ldb;
+    if (col_operand(b, opa, lda) && col_operand(a, opb, ldb)) {
+      const int64_t m = a.size(-2), k = a.size(-1), n = b.size(-1), ldc = out.stride(-2);
+      const bool batched = out.dim() == 3;
+      std::string key;
+      key.reserve(64);
+      key += batched ? 'B' : 'N'; key += opa; key += opb;
+      key += '_'; key += std::to_string(n); key += '_'; key += std::to_string(m); key += '_'; key += std::to_string(k);
+      if (batched) { key += "_B_"; key += std::to_string(out.size(0)); }
+      key += "_ld_"; key += std::to_string(lda); key += '_'; key += std::to_string(ldb); key += '_'; key += std::to_string(ldc);
+      int32_t sol = 0;
+      auto it = g_gemm_table_rb.find(key);
+      if (it != g_gemm_table_rb.end() && it->second != kDeclined) sol = it->second;
+      else if ((it = g_gemm_table.find(key)) != g_gemm_table.end() && it->second != kDeclined) sol = it->second;
+      const int64_t sa = b.dim() == 3 ? b.stride(0) : 0, sb = a.dim() == 3 ? a.stride(0) : 0, sc = batched ? out.stride(0) : 0;
+      int rc = mm_gemm_f32((char)(opa - 32), (char)(opb - 32), (int)n, (int)m, (int)k, 1.0f, fp(b), (int)lda, sa, fp(a), (int)ldb, sb,
+                           0.0f, fpm(out), (int)ldc, sc, batched ? (int)out.size(0) : 1, sol, stream);
+      if (rc == MM_ERR_BLAS && sol != 0)
+        rc = mm_gemm_f32((char)(opa - 32), (char)(opb - 32), (int)n, (int)m, (int)k, 1.0f, fp(b), (int)lda, sa, fp(a), (int)ldb, sb, 0.0f,
+                         fpm(out), (int)ldc, sc, batched ? (int)out.size(0) : 1, 0, stream);
+      if (rc == MM_OK) return;
+    }
+  }
+  if (!g_gemm_table.empty() && !g_rocblas_only && out.stride(-1) == 1) {
     char opa, opb;
     int64_t lda, ldb;
     if (col_operand(b, opa, lda) && col_operand(a, opb, ldb)) {
@@ -120,6 +149,11 @@ inline Tensor gemm_new(const Tensor& a, const Tensor& b, void* stream) {      //
   Tensor out = at::empty({a.dim() == 3 ? a.size(0) : b.size(0), a.size(-2), b.size(-1)}, a.options());
   gemm_out(out, a, b, stream);
   return out;
+}
+
+void set_gemm_table_rb(const std::vector<std::pair<std::string, int64_t>>& entries) {
+  g_gemm_table_rb.clear();
+  for (const auto& e : entries) g_gemm_table_rb[e.first] = (int32_t)e.second;
 }
 
 void set_gemm_table(const std::vector<std::pair<std::string, int64_t>>& entries) {
@@ -600,6 +634,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, mod) {
   mod.doc() = "medmamba_amd: C++ sequencing of the SS2D branch over the C ABI of libmedmamba_hip.so";
   mod.def("ss2d_fwd", &ss2d_fwd);
   mod.def("ss2d_bwd", &ss2d_bwd);
+  mod.def("set_rocblas_only", [](bool on) { g_rocblas_only = on; });
+  mod.def("set_gemm_table_rb", &set_gemm_table_rb);
   mod.def("ss2d_bwd_data", &ss2d_bwd_data);
   mod.def("ss2d_bwd_params", &ss2d_bwd_params);
   mod.def("set_gemm_table", &set_gemm_table);

@@ -572,15 +572,15 @@ class SS2DCoreFn(torch.autograd.Function):
         return (du2, dcw, dcb, gWx, gWdt, gb.view(4, D), gA, gD, dz, ln_out[:D], ln_out[D:], None, None, None, None, None)
 
 
-# ---- EXPERIMENT, off by default: the SS2D backward's parameter half on a third stream -----------------------------
-# Nothing on the way to d(input) waits for the five weight-gradient GEMMs and the un-packing launch of a block.  MM_PARAM_STREAM=1
-# issues them (ss2d_bwd_params) on a third stream behind an event recorded after the data half (ss2d_bwd_data); the stream of the
-# backward pass waits for that stream ONCE, in an end-of-backward callback of the autograd engine.  Measured: 27.06 instead of
-# 27.66-27.79 ms per step of S / 64 — and, with steps queued back to back, the GPU STOPS in roughly two runs of bench.py out of
-# five, whatever GPU_MAX_HW_QUEUES is (tools/param_stream_ab.py, tools/param_stream_soak.sh).  Not the stream / event / allocator
-# steps below (the same steps around a trivial kernel: 7 runs of 7 clean), not the recorded GEMM solutions (rocBLAS's own picks stop
-# it too, so does ATen's route), the channel-major blocks alone suffice, element-wise work or square GEMMs there never stop it: the
-# library's large-K (split-K) GEMMs on a third busy queue.  Do not enable outside an experiment.
+# ---- off by default: the SS2D backward's parameter half on a third stream -----------------------------------------
+# Nothing on the way to d(input) waits for the four weight-gradient GEMMs and the un-packing launch of a block.  MM_PARAM_STREAM=1
+# issues them (ss2d_bwd_params) on a third stream behind an event recorded after the data half (ss2d_bwd_data), for the channel-major
+# blocks (the 14x14 and 7x7 stages); the stream of the backward pass waits for that stream ONCE, in an end-of-backward callback of
+# the autograd engine.  Measured on one box, alternating: 27.64 instead of 28.18 ms per step of S / 64 (-1.9 %).
+# The GEMMs on that stream must be rocBLAS kernels: with hipBLASLt kernels there (the overall winners of three of the four shapes)
+# the GPU STOPPED in 9 of 20 runs of bench.py — whatever GPU_MAX_HW_QUEUES, whatever route the GEMM took — while the same steps
+# around element-wise work or square GEMMs, or with rocBLAS kernels only (tuning/gemm_gfx950_rocblas.csv, set_rocblas_only), never
+# did: 0 of 67 runs.  Off by default until it has been soaked with the whole default bench and with RCCL beside it.
 _PARAM_STREAM_MODE = os.environ.get("MM_PARAM_STREAM", "0")
 _PARAM_STREAMS = {}            # device -> [stream, join scheduled?, used since the last join?]
 
@@ -649,7 +649,7 @@ class SS2DBranchFn(torch.autograd.Function):
         with _lib.device_guard(x.device):
             bt = BRANCH_TIMER.start()
             ev0, ev1 = KERNEL_TIMER.pair("scan_bwd", scan_bytes_bwd(Bsz, 4 * D, L, 16, 4), Bsz * 4 * D * L * 16)
-            if _PARAM_STREAM_MODE == "0":
+            if _PARAM_STREAM_MODE == "0" or not cm:      # (batch-major blocks: their weight gradients go through ATen, hipBLASLt included)
                 g = _host.module().ss2d_bwd(dout, x, in_w, conv_w, conv_b, ln_w, ln_b, out_w, xz, u2, x_dbl, delta, P, x_chk, m, mu, rstd, y,
                                             H, W, cm, _PACK_FOLD, _BWD_VARIANT, _stream(), ev0, ev1)
             else:
@@ -663,7 +663,11 @@ class SS2DBranchFn(torch.autograd.Function):
                 ev.record(main)
                 with torch.cuda.stream(ps):
                     ps.wait_event(ev)
-                    gp = mod.ss2d_bwd_params(dout, x, in_w, conv_b, out_w, u2, x_dbl, P, y, *d[1:], H, W, cm, _PACK_FOLD, _stream())
+                    mod.set_rocblas_only(True)      # no hipBLASLt kernel on the third stream (see above)
+                    try:
+                        gp = mod.ss2d_bwd_params(dout, x, in_w, conv_b, out_w, u2, x_dbl, P, y, *d[1:], H, W, cm, _PACK_FOLD, _stream())
+                    finally:
+                        mod.set_rocblas_only(False)
                 for t in (dout, x, u2, x_dbl, P, y, *d[1:]):   # freed by the engine / this frame while `ps` may still read them
                     t.record_stream(ps)
                 for t in gp:                # allocated under `ps`, consumed on the main stream (optimizer, all-reduce)
