@@ -119,6 +119,11 @@ def clear():
     from . import _host
     if _host.module() is not None:
         _host.module().set_gemm_table([])
+        _host.module().set_gemm_table_rb([])
+    import sys
+    ops = sys.modules.get(__package__ + ".ops")
+    if ops is not None:
+        ops._PARAM_COVERED.clear()        # (MM_PARAM_STREAM: which blocks' weight-gradient GEMMs have rocBLAS records)
 
 
 def _operand(t):

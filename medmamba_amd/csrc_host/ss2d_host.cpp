@@ -156,6 +156,25 @@ void set_gemm_table_rb(const std::vector<std::pair<std::string, int64_t>>& entri
   for (const auto& e : entries) g_gemm_table_rb[e.first] = (int32_t)e.second;
 }
 
+// Are the four weight-gradient GEMMs of a channel-major block (ss2d_bwd_params, cm = true) all covered by an EXPLICIT rocBLAS solution?
+// Only then may that half run on a stream of its own (ops.py, MM_PARAM_STREAM): rocBLAS's own pick (solution 0) may be a hipBLASLt kernel.
+bool ss2d_params_covered(int64_t Bsz, int64_t L, int64_t dm, int64_t D, int64_t C, int64_t R) {
+  const std::string Q = std::to_string(Bsz * L), sD = std::to_string(D), sdm = std::to_string(dm);
+  const std::string keys[4] = {
+      "Ntn_" + sD + "_" + sdm + "_" + Q + "_ld_" + Q + "_" + Q + "_" + sD,                                             // d(out_proj.weight)
+      "Btn_" + std::to_string(R) + "_" + sD + "_" + Q + "_B_4_ld_" + Q + "_" + Q + "_" + std::to_string(R),             // d(dt_projs_weight)
+      "Btn_" + sD + "_" + std::to_string(2 * C) + "_" + Q + "_B_2_ld_" + Q + "_" + Q + "_" + sD,                        // d(x_proj_weight)
+      "Nnn_" + sdm + "_" + std::to_string(2 * D) + "_" + Q + "_ld_" + sdm + "_" + Q + "_" + sdm};                       // d(in_proj.weight)
+  for (const auto& k : keys) {
+    auto it = g_gemm_table_rb.find(k);
+    if (it != g_gemm_table_rb.end() && it->second != kDeclined) continue;
+    it = g_gemm_table.find(k);
+    if (it != g_gemm_table.end() && it->second != kDeclined) continue;
+    return false;
+  }
+  return true;
+}
+
 void set_gemm_table(const std::vector<std::pair<std::string, int64_t>>& entries) {
   g_gemm_table.clear();
   for (const auto& e : entries) g_gemm_table.emplace(e.first, (int32_t)e.second);
@@ -636,6 +655,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, mod) {
   mod.def("ss2d_bwd", &ss2d_bwd);
   mod.def("set_rocblas_only", [](bool on) { g_rocblas_only = on; });
   mod.def("set_gemm_table_rb", &set_gemm_table_rb);
+  mod.def("ss2d_params_covered", &ss2d_params_covered);
   mod.def("ss2d_bwd_data", &ss2d_bwd_data);
   mod.def("ss2d_bwd_params", &ss2d_bwd_params);
   mod.def("set_gemm_table", &set_gemm_table);

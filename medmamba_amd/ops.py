@@ -583,6 +583,7 @@ class SS2DCoreFn(torch.autograd.Function):
 # did: 0 of 83 runs.  Off by default until it has been soaked through the test suite and with RCCL beside it.
 _PARAM_STREAM_MODE = os.environ.get("MM_PARAM_STREAM", "0")
 _PARAM_STREAMS = {}            # device -> [stream, join scheduled?, used since the last join?]
+_PARAM_COVERED = {}            # (batch, L, d_model, d_inner, rows of x_dbl) -> the block's four weight-gradient GEMMs have rocBLAS records
 
 
 def _param_state(device):
@@ -649,7 +650,13 @@ class SS2DBranchFn(torch.autograd.Function):
         with _lib.device_guard(x.device):
             bt = BRANCH_TIMER.start()
             ev0, ev1 = KERNEL_TIMER.pair("scan_bwd", scan_bytes_bwd(Bsz, 4 * D, L, 16, 4), Bsz * 4 * D * L * 16)
-            if _PARAM_STREAM_MODE == "0" or not cm:      # (batch-major blocks: their weight gradients go through ATen, hipBLASLt included)
+            ps_ok = _PARAM_STREAM_MODE != "0" and cm     # (batch-major blocks: their weight gradients go through ATen, hipBLASLt included)
+            if ps_ok:           # ... and only with an explicit rocBLAS solution on record for each of the four GEMMs
+                key = (Bsz, L, x.shape[2], D, x_dbl.shape[1])
+                ps_ok = _PARAM_COVERED.get(key)
+                if ps_ok is None:
+                    ps_ok = _PARAM_COVERED[key] = bool(_host.module().ss2d_params_covered(Bsz, L, x.shape[2], D, x_dbl.shape[1], x_dbl.shape[1] - 32))
+            if not ps_ok:
                 g = _host.module().ss2d_bwd(dout, x, in_w, conv_w, conv_b, ln_w, ln_b, out_w, xz, u2, x_dbl, delta, P, x_chk, m, mu, rstd, y,
                                             H, W, cm, _PACK_FOLD, _BWD_VARIANT, _stream(), ev0, ev1)
             else:
