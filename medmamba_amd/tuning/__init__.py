@@ -6,6 +6,9 @@ hipBLASLt's default heuristics pick poor kernels for several of the skinny fp32 
 image's ROCm 7.2 / hipBLASLt / rocBLAS builds (`tools/tune_gemms.py` regenerates it).  TunableOp validates the library
 versions and the GPU architecture recorded in the file and ignores it on any mismatch; shapes that are not in the file
 run with the default heuristic — nothing is tuned at run time unless `tune=True`.
+`gemm_gfx950_rocblas.csv` (read by `blas.load_table` next to the default file) holds rocBLAS-ONLY winners for the weight-gradient GEMMs
+of the channel-major SS2D blocks whose overall winner is a hipBLASLt kernel: what `MM_PARAM_STREAM=1` runs on its third stream, where
+hipBLASLt kernels stop the GPU (`tools/tune_param_gemms.py`, `tools/tune_param_gemms_rocblas.py`).
 """
 import os
 
