@@ -223,3 +223,45 @@ def test_recorded_split_k_solutions_on_two_streams_at_once():
                         assert torch.equal(torch.isfinite(C), ok) and float((C[ok] - want[ok]).abs().max()) <= 1e-5 * scale, key
     finally:
         blas.clear()
+
+
+def test_rocblas_only_records_cover_the_channel_major_blocks_of_S_and_nothing_else():
+    """MM_PARAM_STREAM (off by default) may move a block's weight-gradient GEMMs to a third stream only when each of the
+    four has an EXPLICIT rocBLAS solution on record (rocBLAS's own pick may be a hipBLASLt kernel, and those stop the GPU from a third
+    queue): the records (gemm_gfx950.csv + gemm_gfx950_rocblas.csv) cover the 14x14 and 7x7 blocks of MedMamba-T / S at 64 images, not
+    a shape nobody tuned, and every rocBLAS-only record runs and agrees with torch."""
+    import csv
+    import os
+    from medmamba_amd import _host, _lib, blas
+    from medmamba_amd.tuning import DEFAULT_FILE, enable_tuned_gemms
+    enable_tuned_gemms()
+    if not blas._TABLE or _host.module() is None:
+        pytest.skip("GEMM table not recorded for this rocBLAS build / no C++ layer")
+    try:
+        cov = _host.module().ss2d_params_covered
+        assert cov(64, 196, 192, 384, 44, 12) and cov(64, 49, 384, 768, 56, 24)
+        assert not cov(32, 576, 256, 512, 48, 16) and not cov(64, 196, 192, 384, 44, 11) and not cov(7, 196, 192, 384, 44, 12)
+        rows = list(csv.reader(open(os.path.join(os.path.dirname(DEFAULT_FILE), "gemm_gfx950_rocblas.csv"))))
+        recs = [r for r in rows if len(r) >= 3 and r[2].startswith("Gemm_Rocblas_")]
+        assert len(recs) >= 8
+        g = torch.Generator(device=DEV).manual_seed(1)
+        for r in recs:
+            p = r[1].split("_")
+            opa, opb, n, m, k = p[0][0], p[0][1], int(p[1]), int(p[2]), int(p[3])
+            batch = int(p[5]) if p[4] == "B" else 1
+            lda, ldb, ldc = (int(v) for v in p[-3:])
+            A = torch.randn(batch, (k if opa == "n" else n) * lda, device=DEV, generator=g)       # column-major operands, as rocBLAS sees them
+            B = torch.randn(batch, (m if opb == "n" else k) * ldb, device=DEV, generator=g)
+            C = torch.empty(batch, m * ldc, device=DEV)
+            rc = _lib.lib().mm_gemm_f32(opa.upper().encode(), opb.upper().encode(), n, m, k, 1.0, A.data_ptr(), lda, A.stride(0), B.data_ptr(),
+                                        ldb, B.stride(0), 0.0, C.data_ptr(), ldc, C.stride(0), batch, int(r[2][len("Gemm_Rocblas_"):]),
+                                        _lib.raw_stream())
+            assert rc == 0, (r[1], rc)
+            Aop = A.view(batch, -1, lda)[:, :k, :n].transpose(1, 2) if opa == "n" else A.view(batch, -1, lda)[:, :n, :k]       # (b, n, k)
+            Bop = B.view(batch, -1, ldb)[:, :m, :k].transpose(1, 2) if opb == "n" else B.view(batch, -1, ldb)[:, :k, :m]       # (b, k, m)
+            want = torch.bmm(Aop.double(), Bop.double()).transpose(1, 2).float()                  # C^T rows: (b, m, n)
+            got = C.view(batch, m, ldc)[:, :, :n]
+            assert (got - want).abs().max().item() <= 2e-3 * max(1.0, want.abs().max().item()), r[1]
+    finally:
+        blas.clear()
+        torch.cuda.tunable.enable(False)
