@@ -580,7 +580,7 @@ class SS2DCoreFn(torch.autograd.Function):
 # The GEMMs on that stream must be rocBLAS kernels: with hipBLASLt kernels there (the overall winners of three of the four shapes)
 # the GPU STOPPED in 9 of 20 runs of bench.py — whatever GPU_MAX_HW_QUEUES, whatever route the GEMM took — while the same steps
 # around element-wise work or square GEMMs, or with rocBLAS kernels only (tuning/gemm_gfx950_rocblas.csv, set_rocblas_only), never
-# did: 0 of 83 runs.  Off by default until it has been soaked through the test suite and with RCCL beside it.
+# did: 0 of 107 runs.  Off by default until it has been soaked through the test suite and with RCCL beside it.
 _PARAM_STREAM_MODE = os.environ.get("MM_PARAM_STREAM", "0")
 _PARAM_STREAMS = {}            # device -> [stream, join scheduled?, used since the last join?]
 _PARAM_COVERED = {}            # (batch, L, d_model, d_inner, rows of x_dbl) -> the block's four weight-gradient GEMMs have rocBLAS records
