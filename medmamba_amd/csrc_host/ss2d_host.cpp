@@ -59,7 +59,7 @@ inline Tensor rows(const Tensor& t) { return t.stride(-1) == 1 ? t : t.contiguou
 std::unordered_map<std::string, int32_t> g_gemm_table;      // filled once by blas.load_table (set_gemm_table); afterwards only a value
                                                              // may change, to kDeclined (a solution the library rejected)
 constexpr int32_t kDeclined = INT32_MIN;
-bool g_rocblas_only = false;      // set around the parameter half when it runs on its own stream (ops.py, MM_PARAM_STREAM)
+thread_local bool g_rocblas_only = false;      // set (per host thread) around the parameter half when it runs on its own stream (ops.py, MM_PARAM_STREAM)
 std::unordered_map<std::string, int32_t> g_gemm_table_rb;   // rocBLAS-only winners for shapes whose overall winner is a hipBLASLt kernel
 
 inline bool col_operand(const Tensor& t, char& op, int64_t& ld) {
